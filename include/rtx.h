@@ -1,0 +1,159 @@
+/* rtx.h — C ABI of the MI355X trace-and-shade library (librtx_hip.so).
+ *
+ * This is the drop-in boundary for the body of the reference's
+ *   Camera::render(&World) -> Canvas            (/root/reference/src/camera.rs:39-54)
+ * i.e. everything inside the pixel loop camera.rs:45-51 (ray_for_pixel :56-69,
+ * World::color_at world.rs:100-323) plus the 8-bit quantisation the Canvas is
+ * only ever consumed through (canvas.rs:45-53, color.rs:40-48).
+ *
+ * The reference has no FFI/plugin interface of its own; these
+ * entry points are what a Rust `extern "C"` block inside the crate would bind
+ * (INTEGRATION.md shows that binding).  The host flattens its World
+ * (object_store.rs:185-192, group.rs:16-19, csg.rs:29-33) into the
+ * structure-of-arrays `rtx_scene_desc`: inverse transforms, primitive records,
+ * group/CSG bounds, CSG trees, pattern parameters.  Plain pointers and sizes
+ * only; the caller owns every array it passes; the library copies what it
+ * needs at rtx_scene_create().
+ *
+ * All matrices: 16 doubles, COLUMN-major (nalgebra storage: m[c*4+r]).
+ * All arithmetic on the device is f64 with the reference's operation order.
+ * Not thread-safe per context (the reference is single-threaded, main.rs:11-28).
+ */
+#ifndef RTX_H
+#define RTX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes (the reference panics / unwrap()s instead: main.rs:21,27) */
+enum {
+    RTX_OK = 0,
+    RTX_E_INVALID = -1,      /* NULL / out-of-range argument, malformed scene graph */
+    RTX_E_DEVICE = -2,       /* HIP runtime error (rtx_last_error() has the text) */
+    RTX_E_CAPACITY = -3,     /* scene exceeds a bounded-list / nesting limit of the kernel */
+    RTX_E_UNSUPPORTED = -4   /* e.g. non-affine (projective) transform */
+};
+
+/* node kinds: ShapeTypeMarker (shapes/mod.rs:84-89) + Group (group.rs) + CSG (csg.rs) */
+enum { RTX_NODE_SPHERE = 0, RTX_NODE_PLANE = 1, RTX_NODE_CUBE = 2, RTX_NODE_GROUP = 3, RTX_NODE_CSG = 4 };
+/* CsgOperator (csg.rs:22-26) */
+enum { RTX_CSG_UNION = 0, RTX_CSG_INTERSECTION = 1, RTX_CSG_DIFFERENCE = 2 };
+/* PatternData (patterns.rs:66-73) */
+enum { RTX_PAT_PLAIN = 0, RTX_PAT_STRIPES = 1, RTX_PAT_RINGS = 2, RTX_PAT_CHECKERS = 3,
+       RTX_PAT_GRADIENT = 4, RTX_PAT_TEST = 5 };
+
+/* limits of the bounded per-thread structures (validated by rtx_scene_create) */
+#define RTX_MAX_DEPTH        8    /* reflection/refraction budget; the reference hard-codes 5 (camera.rs:42) */
+#define RTX_MAX_LEVELS      16    /* container nesting depth (groups/CSGs) */
+#define RTX_MAX_CSG_ENTRIES 16    /* hits collected under one CSG root = 2 x leaf shapes */
+#define RTX_MAX_CSG_NEST     8    /* containers nested inside one CSG root */
+#define RTX_TILE             8    /* 8x8 pixel tile = one wavefront; band = RTX_TILE rows */
+
+/* Material (material.rs:11-14) = Shader (material.rs:30-38) + Pattern (patterns.rs:9-12) */
+typedef struct rtx_material {
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    double color_a[3], color_b[3];       /* plain: a; two-colour patterns: a, b */
+    double pattern_inverse[16];          /* inverse(pattern.transform) (object_store.rs:297) */
+    int32_t pattern_kind;                /* RTX_PAT_* */
+    int32_t _pad;
+} rtx_material;
+
+/* Flattened World.  One entry per node (shape, group or CSG) in any order. */
+typedef struct rtx_scene_desc {
+    int32_t n_nodes;
+    const int32_t* node_kind;            /* RTX_NODE_* */
+    const double*  node_inverse;         /* n_nodes*16: inverse(transform) (object_store.rs:244-245) */
+    const double*  node_bounds;          /* n_nodes*6 {min xyz, max xyz}: local bounds of groups/CSGs
+                                            as computed by set_bounds_of (object_store.rs:360-389);
+                                            NaN = empty axis (bounds.rs:23-27); ignored for shapes */
+    const int32_t* node_first_child;     /* groups: range into children[] in insertion order     */
+    const int32_t* node_child_count;     /*   (group.rs:17,70); CSG: exactly 2 = {left, right}   */
+    const int32_t* node_csg_op;          /* CSG: RTX_CSG_*; else ignored */
+    const int32_t* node_shape_index;     /* shapes: reference ShapeIndex (reported as hit id) */
+    const int32_t* node_material;        /* shapes: index into materials[] */
+    int32_t n_children;
+    const int32_t* children;             /* node ids */
+    int32_t n_roots;
+    const int32_t* roots;                /* World.scene in order (world.rs:82,113) */
+    int32_t n_materials;
+    const rtx_material* materials;
+    int32_t n_lights;
+    const double* light_position;        /* n_lights*3 (light.rs:8-11) */
+    const double* light_intensity;       /* n_lights*3 */
+} rtx_scene_desc;
+
+/* Camera (camera.rs:10-17) with the inverse precomputed (camera.rs:65-66) */
+typedef struct rtx_camera {
+    int32_t hsize, vsize;
+    double pixel_size, half_width, half_height;
+    double inverse[16];                  /* inverse(camera.transform) */
+} rtx_camera;
+
+/* event counters: same meaning as the oracle's (oracle/rt_oracle.h) */
+enum {
+    RTX_EV_XFORM = 0, RTX_EV_SPHERE, RTX_EV_PLANE, RTX_EV_CUBE, RTX_EV_BOUNDS, RTX_EV_CSG_ENTRIES,
+    RTX_EV_HIT, RTX_EV_LEVELS, RTX_EV_LIGHT, RTX_EV_POW, RTX_EV_REFR, RTX_EV_SCHLICK,
+    RTX_EV_COUNT = 16
+};
+
+typedef struct rtx_stats {
+    uint64_t rays_primary, rays_shadow, rays_secondary;   /* 1 per color_at (world.rs:100) / is_shadowed (world.rs:195) */
+    uint64_t ev[RTX_EV_COUNT];           /* filled only with RTX_F_COUNT_EVENTS */
+    uint64_t overflow_pixels;            /* pixels that hit a bounded-list limit (then RTX_E_CAPACITY) */
+    double   kernel_ms;                  /* hipEvent time of the trace_shade launch */
+} rtx_stats;
+
+/* render flags */
+enum {
+    RTX_F_COUNT_EVENTS = 1,              /* run the event-counting kernel variant */
+    RTX_F_NO_SHADOW_EARLY_OUT = 2,       /* traverse the whole scene for shadow rays (as the reference does) */
+    RTX_F_BANDS_COMPACT = 4              /* write this rank's bands back-to-back instead of at image rows */
+};
+
+/* Which rows to render: 8-row bands b = first, first+stride, ... (row-interleaved tile bands,
+ * one residue class per GPU).  {0,1} = whole image. */
+typedef struct rtx_bands { int32_t first, stride; } rtx_bands;
+
+typedef struct rtx_ctx rtx_ctx;
+typedef struct rtx_scene rtx_scene;
+
+/* Binds a context to one HIP device (one process per GPU).  Replaces nothing in the
+ * reference (it has no device); called once before the first Camera::render (main.rs:24). */
+int  rtx_init(int device, rtx_ctx** out);
+void rtx_shutdown(rtx_ctx*);
+
+/* Uploads a flattened World: what `&World` is to Camera::render (camera.rs:39).
+ * Compiles the graph into the kernel's traversal program and validates the bounded-list limits. */
+int  rtx_scene_create(rtx_ctx*, const rtx_scene_desc*, rtx_scene** out);
+void rtx_scene_destroy(rtx_scene*);
+
+/* Camera::render (camera.rs:39-54) + Canvas::to_image (canvas.rs:45-53): renders the selected
+ * bands and copies RGB8 (and optional primary-hit ShapeIndex per pixel, -1 = miss) to host
+ * buffers of hsize*vsize*3 bytes / hsize*vsize int32 (rows outside the bands are untouched;
+ * with RTX_F_BANDS_COMPACT the buffers hold rtx_band_rows() rows).  hit may be NULL. */
+int  rtx_render(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
+                uint32_t flags, uint8_t* rgb, int32_t* hit, rtx_stats* stats);
+
+/* Same, but the outputs are DEVICE pointers on the context's device and the launch is queued on
+ * `stream` (a hipStream_t, NULL = the context's own stream) without a host copy; used when the
+ * caller gathers bands with RCCL.  Synchronises only if stats != NULL. */
+int  rtx_render_device(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
+                       uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats);
+
+/* rows (padded to whole bands) a rank holds under `bands`, i.e. the compact buffer height */
+int  rtx_band_rows(int vsize, rtx_bands bands);
+
+/* Diagnostic with no counterpart in the reference: evaluates one f64 library operation per element
+ * on the device so tests can compare the GPU's sqrt / division / pow / floor / round bits with the
+ * host's.  op: 0 sqrt(a), 1 a/b, 2 pow(a,b), 3 floor(a), 4 round(a), 5 fmax(a,b), 6 fmin(a,b).
+ * a, b, out are HOST arrays of n doubles. */
+int  rtx_debug_math(rtx_ctx*, int op, int64_t n, const double* a, const double* b, double* out);
+
+const char* rtx_strerror(int code);
+const char* rtx_last_error(const rtx_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,7 +23,11 @@ namespace {
 
 const double INF = std::numeric_limits<double>::infinity();
 const double NaN = std::numeric_limits<double>::quiet_NaN();
-const double TIE_EPS = 1e-9;
+// EPSILON-tie thresholds: far above f64 rounding noise (1e-16 relative), far below the
+// reference's own 1e-10 surface offset (world.rs:298-300) so that by-design near-zero
+// self-intersections of shadow/secondary rays are not flagged.
+const double TIE_EPS = 1e-11;     // relative gap between competing t's / pattern cell borders
+const double TIE_ZERO = 1e-12;    // |t| this close to 0 could flip the t >= 0 test
 
 // ---------------------------------------------------------------- nalgebra
 struct V3 { double x, y, z; };            // Point3 / Vector3 (geometry.rs:7-8)
@@ -675,8 +679,8 @@ struct ora_world {
         if (!g_cnt) return;
         bool t = false;
         double th = xs[h].t;
-        if (th <= TIE_EPS) t = true;                                       // could flip sign
-        if (h > 0 && xs[h - 1].t >= -TIE_EPS) t = true;
+        if (th <= TIE_ZERO) t = true;                                      // could flip sign
+        if (h > 0 && xs[h - 1].t >= -TIE_ZERO) t = true;
         for (size_t k = h + 1; k < xs.size(); k++) {
             if (xs[k].t - th > TIE_EPS * std::fmax(1.0, std::fabs(th))) break;
             if (xs[k].shape != xs[h].shape) { t = true; break; }
@@ -729,7 +733,7 @@ struct ora_world {
         int h = hit_index(xs);
         if (hit_shape) *hit_shape = (h >= 0) ? xs[h].shape : -1;
         if (h < 0) {
-            if (g_cnt && !xs.empty() && xs.back().t >= -TIE_EPS) { g_cnt->tie = true; if (hit_shape) g_cnt->tie_id = true; }
+            if (g_cnt && !xs.empty() && xs.back().t >= -TIE_ZERO) { g_cnt->tie = true; if (hit_shape) g_cnt->tie_id = true; }
             return BLACK;
         }
         tie_check_hit(xs, h, hit_shape != nullptr);

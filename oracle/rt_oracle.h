@@ -157,7 +157,7 @@ void ora_ray_for_pixel(const ora_camera*, int x, int y, double* o3, double* d3);
 /* Camera::render restricted to the pixel list (x[i],y[i]), i<n; pass NULL,NULL,0 for the
  * whole image.  Outputs are indexed by i (or by x+y*hsize for the whole image); any may be
  * NULL.  hit_id = ShapeIndex of the primary hit, -1 = miss.  tie = 1 if any decision on the
- * pixel's ray tree was within 1e-9 of flipping (EPSILON-tie pixel), bit1 = primary-hit-id tie.
+ * pixel's ray tree was within 1e-11 (relative) of flipping (EPSILON-tie pixel), bit1 = primary-hit-id tie.
  * threads <= 1 reproduces the reference's single-threaded loop. */
 int  ora_render(ora_world*, const ora_camera*, int max_depth,
                 const int32_t* xs, const int32_t* ys, int64_t n,

@@ -1,0 +1,425 @@
+// rtx_api.hip — implementation of the C ABI in include/rtx.h: scene compiler
+// (rtx_scene_desc -> traversal program), device memory management, launch, stats.
+//
+// There is NO CPU fallback: every entry point fails with RTX_E_DEVICE when HIP
+// cannot provide a device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+
+extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
+                                             uint8_t* rgb, int32_t* hit, unsigned long long* counters,
+                                             int count_events, hipStream_t stream);
+
+__global__ void debug_math_kernel(int op, long long n, const double* a, const double* b, double* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = a[i], y = b[i], r;
+    switch (op) {
+        case 0: r = __builtin_sqrt(x); break;
+        case 1: r = x / y; break;
+        case 2: r = pow(x, y); break;
+        case 3: r = __builtin_floor(x); break;
+        case 4: r = __builtin_round(x); break;
+        case 5: r = __builtin_fmax(x, y); break;
+        default: r = __builtin_fmin(x, y); break;
+    }
+    out[i] = r;
+}
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* d_counters = nullptr;
+    uint8_t* d_rgb = nullptr; size_t rgb_cap = 0;
+    int32_t* d_hit = nullptr; size_t hit_cap = 0;
+    std::string err;
+};
+
+struct rtx_scene {
+    rtx_ctx* ctx = nullptr;
+    SceneDev dev{};
+    void* d_ops = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
+    void* d_materials = nullptr; void* d_lights = nullptr;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            return RTX_E_DEVICE;                                                       \
+        }                                                                              \
+    } while (0)
+
+int fail(rtx_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+// column-major 4x4 -> rows 0..2 (row-major 3x4) + w33; false if the bottom row is not (0,0,0,*)
+bool affine_rows(const double* m, double* rows12, double* w33) {
+    for (int c = 0; c < 3; c++) if (!(m[c * 4 + 3] == 0.0)) return false;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) rows12[r * 4 + c] = m[c * 4 + r];
+    *w33 = m[15];
+    return true;
+}
+
+struct Compiler {
+    const rtx_scene_desc* d;
+    std::vector<OpRec> ops;
+    std::vector<ShapeRec> shapes;
+    std::vector<int32_t> paths;
+    std::vector<int32_t> stack;      // op indices of the ancestors (root first)
+    std::vector<char> seen;
+    int max_container_level = -1;
+    bool has_csg = false;
+    int err = RTX_OK;
+    std::string msg;
+
+    bool bad(int code, const std::string& m) { if (err == RTX_OK) { err = code; msg = m; } return false; }
+
+    OpRec make(int node, int kind, int level, int flags, int clevel) {
+        OpRec o; std::memset(&o, 0, sizeof o);
+        o.kind = kind; o.level = level; o.flags = flags; o.clevel = clevel;
+        if (node >= 0) {
+            if (!affine_rows(d->node_inverse + (size_t)node * 16, o.inv, &o.w33))
+                bad(RTX_E_UNSUPPORTED, "node " + std::to_string(node) + ": transform is not affine");
+            if (!(o.w33 == 1.0)) o.flags |= OPF_DIV;
+            if (d->node_bounds) std::memcpy(o.bounds, d->node_bounds + (size_t)node * 6, sizeof o.bounds);
+        }
+        return o;
+    }
+
+    // returns the number of list entries the subtree can produce (for the CSG capacity check)
+    int emit(int node, int level, bool list, int clevel) {
+        if (err != RTX_OK) return 0;
+        if (node < 0 || node >= d->n_nodes) { bad(RTX_E_INVALID, "node id out of range"); return 0; }
+        if (seen[node]) { bad(RTX_E_INVALID, "node " + std::to_string(node) + " reachable twice (not a tree)"); return 0; }
+        seen[node] = 1;
+        if (level >= RTX_MAX_LEVELS) { bad(RTX_E_CAPACITY, "container nesting deeper than RTX_MAX_LEVELS"); return 0; }
+        const int kind = d->node_kind[node];
+        const int lf = list ? OPF_LIST : 0;
+        if (kind == RTX_NODE_SPHERE || kind == RTX_NODE_PLANE || kind == RTX_NODE_CUBE) {
+            OpRec o = make(node, kind, level, lf, clevel);
+            const int si = d->node_shape_index[node];
+            if (si < 0) { bad(RTX_E_INVALID, "negative shape index"); return 0; }
+            const int mi = d->node_material[node];
+            if (mi < 0 || mi >= d->n_materials) { bad(RTX_E_INVALID, "material index out of range"); return 0; }
+            o.shape = si;
+            const int me = (int)ops.size();
+            ops.push_back(o);
+            if ((size_t)si >= shapes.size()) shapes.resize(si + 1, ShapeRec{-1, 0, 0, 0});
+            if (shapes[si].type != -1) { bad(RTX_E_INVALID, "duplicate shape index"); return 0; }
+            ShapeRec s; s.type = kind; s.material = mi; s.path_begin = (int)paths.size();
+            for (int a : stack) paths.push_back(a);
+            paths.push_back(me);
+            s.path_len = (int)stack.size() + 1;
+            shapes[si] = s;
+            return kind == RTX_NODE_PLANE ? 1 : 2;
+        }
+        if (kind != RTX_NODE_GROUP && kind != RTX_NODE_CSG) { bad(RTX_E_INVALID, "unknown node kind"); return 0; }
+        const int fc = d->node_first_child[node], nc = d->node_child_count[node];
+        if (nc < 0 || fc < 0 || fc + nc > d->n_children) { bad(RTX_E_INVALID, "children range out of bounds"); return 0; }
+        if (level > max_container_level) max_container_level = level;
+        int entries = 0;
+        if (kind == RTX_NODE_GROUP) {
+            if (list && clevel >= RTX_MAX_CSG_NEST) { bad(RTX_E_CAPACITY, "containers nested too deep inside a CSG"); return 0; }
+            const int b = (int)ops.size();
+            ops.push_back(make(node, OPK_GROUP_BEGIN, level, lf, clevel));
+            stack.push_back(b);
+            for (int i = 0; i < nc; i++) entries += emit(d->children[fc + i], level + 1, list, clevel + 1);
+            stack.pop_back();
+            ops.push_back(make(-1, OPK_GROUP_END, level, lf, clevel));
+            ops[b].skip = (int)ops.size();
+        } else {
+            if (nc != 2) { bad(RTX_E_INVALID, "CSG node needs exactly 2 children"); return 0; }
+            const int cop = d->node_csg_op[node];
+            if (cop < 0 || cop > 2) { bad(RTX_E_INVALID, "unknown CSG operator"); return 0; }
+            has_csg = true;
+            const bool root = !list;
+            const int cl = root ? 0 : clevel;
+            if (cl >= RTX_MAX_CSG_NEST) { bad(RTX_E_CAPACITY, "containers nested too deep inside a CSG"); return 0; }
+            const int f = OPF_LIST | (root ? OPF_ROOT : 0);
+            const int b = (int)ops.size();
+            OpRec ob = make(node, OPK_CSG_BEGIN, level, f, cl); ob.shape = cop;
+            ops.push_back(ob);
+            stack.push_back(b);
+            entries += emit(d->children[fc], level + 1, true, cl + 1);
+            OpRec om = make(-1, OPK_CSG_MID, level, f, cl); om.shape = cop; ops.push_back(om);
+            entries += emit(d->children[fc + 1], level + 1, true, cl + 1);
+            stack.pop_back();
+            OpRec oe = make(-1, OPK_CSG_END, level, f, cl); oe.shape = cop; ops.push_back(oe);
+            ops[b].skip = (int)ops.size();
+            if (root && entries > RTX_MAX_CSG_ENTRIES)
+                bad(RTX_E_CAPACITY, "CSG root can produce " + std::to_string(entries) + " hits > RTX_MAX_CSG_ENTRIES");
+        }
+        return entries;
+    }
+};
+
+template <typename T>
+int upload(rtx_ctx* ctx, const std::vector<T>& v, void** out) {
+    *out = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIPCHK(ctx, hipMalloc(out, bytes));
+    if (!v.empty()) HIPCHK(ctx, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RTX_OK;
+}
+
+int local_bands(int vsize, rtx_bands b) {
+    const int total = (vsize + RTX_TILE - 1) / RTX_TILE;
+    if (b.first >= total) return 0;
+    return (total - b.first + b.stride - 1) / b.stride;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtx_strerror(int code) {
+    switch (code) {
+        case RTX_OK: return "ok";
+        case RTX_E_INVALID: return "invalid argument or malformed scene";
+        case RTX_E_DEVICE: return "HIP device error";
+        case RTX_E_CAPACITY: return "scene exceeds a bounded-list limit of the kernel";
+        case RTX_E_UNSUPPORTED: return "unsupported scene feature";
+        default: return "unknown error";
+    }
+}
+
+const char* rtx_last_error(const rtx_ctx* c) { return c ? c->err.c_str() : ""; }
+
+int rtx_init(int device, rtx_ctx** out) {
+    if (!out) return RTX_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RTX_E_DEVICE;
+    rtx_ctx* c = new rtx_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, RTX_CNT_TOTAL * sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return RTX_E_DEVICE;
+    }
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_shutdown(rtx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    if (c->d_hit) (void)hipFree(c->d_hit);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
+    if (!ctx || !d || !out) return RTX_E_INVALID;
+    *out = nullptr;
+    if (d->n_nodes < 0 || d->n_roots < 0 || d->n_materials < 0 || d->n_lights < 0 || d->n_children < 0)
+        return fail(ctx, RTX_E_INVALID, "negative count");
+    if (d->n_nodes > 0 && (!d->node_kind || !d->node_inverse || !d->node_first_child || !d->node_child_count ||
+                           !d->node_csg_op || !d->node_shape_index || !d->node_material || !d->node_bounds))
+        return fail(ctx, RTX_E_INVALID, "NULL node array");
+    if ((d->n_roots > 0 && !d->roots) || (d->n_children > 0 && !d->children) ||
+        (d->n_materials > 0 && !d->materials) || (d->n_lights > 0 && (!d->light_position || !d->light_intensity)))
+        return fail(ctx, RTX_E_INVALID, "NULL array");
+
+    Compiler cc; cc.d = d; cc.seen.assign(d->n_nodes, 0);
+    for (int i = 0; i < d->n_roots; i++) cc.emit(d->roots[i], 0, false, 0);
+    if (cc.err != RTX_OK) return fail(ctx, cc.err, cc.msg);
+    for (auto& s : cc.shapes) if (s.type == -1) { s.type = OPK_SPHERE; s.path_len = 0; }   // unreachable shapes
+
+    std::vector<MaterialRec> mats(d->n_materials);
+    bool transp = false;
+    for (int i = 0; i < d->n_materials; i++) {
+        const rtx_material& m = d->materials[i];
+        MaterialRec& r = mats[i]; std::memset(&r, 0, sizeof r);
+        r.ambient = m.ambient; r.diffuse = m.diffuse; r.specular = m.specular; r.shininess = m.shininess;
+        r.reflective = m.reflective; r.transparency = m.transparency; r.refractive_index = m.refractive_index;
+        for (int k = 0; k < 3; k++) { r.a[k] = m.color_a[k]; r.b[k] = m.color_b[k]; }
+        if (m.pattern_kind < 0 || m.pattern_kind > RTX_PAT_TEST) return fail(ctx, RTX_E_INVALID, "unknown pattern kind");
+        if (!affine_rows(m.pattern_inverse, r.pinv, &r.pw33)) return fail(ctx, RTX_E_UNSUPPORTED, "pattern transform is not affine");
+        r.kind = m.pattern_kind; r.pdiv = !(r.pw33 == 1.0);
+        if (!(m.transparency == 0.0)) transp = true;
+    }
+    std::vector<LightRec> lights(d->n_lights);
+    for (int i = 0; i < d->n_lights; i++)
+        for (int k = 0; k < 3; k++) { lights[i].pos[k] = d->light_position[i * 3 + k]; lights[i].intensity[k] = d->light_intensity[i * 3 + k]; }
+
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rtx_scene* s = new rtx_scene(); s->ctx = ctx;
+    int rc;
+    if ((rc = upload(ctx, cc.ops, &s->d_ops)) || (rc = upload(ctx, cc.shapes, &s->d_shapes)) ||
+        (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
+        (rc = upload(ctx, lights, &s->d_lights))) {
+        rtx_scene_destroy(s);
+        return rc;
+    }
+    s->dev.ops = (const OpRec*)s->d_ops; s->dev.shapes = (const ShapeRec*)s->d_shapes;
+    s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
+    s->dev.lights = (const LightRec*)s->d_lights;
+    s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
+    s->dev.n_levels = cc.max_container_level + 1;
+    s->dev.has_csg = cc.has_csg ? 1 : 0; s->dev.has_transparency = transp ? 1 : 0;
+    *out = s;
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_ops) (void)hipFree(s->d_ops);
+    if (s->d_shapes) (void)hipFree(s->d_shapes);
+    if (s->d_paths) (void)hipFree(s->d_paths);
+    if (s->d_materials) (void)hipFree(s->d_materials);
+    if (s->d_lights) (void)hipFree(s->d_lights);
+    delete s;
+}
+
+int rtx_debug_math(rtx_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out) {
+    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 6) return RTX_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIPCHK(ctx, hipMalloc((void**)&da, bytes)); HIPCHK(ctx, hipMalloc((void**)&db, bytes)); HIPCHK(ctx, hipMalloc((void**)&dout, bytes));
+    HIPCHK(ctx, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, (long long)n, da, db, dout);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return RTX_OK;
+}
+
+int rtx_band_rows(int vsize, rtx_bands b) {
+    if (vsize <= 0 || b.first < 0 || b.stride < 1) return 0;
+    return local_bands(vsize, b) * RTX_TILE;
+}
+
+int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+                      uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats) {
+    if (!ctx || !scene || !cam || !d_rgb) return RTX_E_INVALID;
+    if (scene->ctx != ctx) return fail(ctx, RTX_E_INVALID, "scene belongs to another context");
+    if (cam->hsize <= 0 || cam->vsize <= 0) return fail(ctx, RTX_E_INVALID, "empty camera");
+    if (max_depth < 0 || max_depth > RTX_MAX_DEPTH) return fail(ctx, RTX_E_CAPACITY, "max_depth exceeds RTX_MAX_DEPTH");
+    if (bands.first < 0 || bands.stride < 1) return fail(ctx, RTX_E_INVALID, "bad band selection");
+
+    CameraDev cd; std::memset(&cd, 0, sizeof cd);
+    cd.hsize = cam->hsize; cd.vsize = cam->vsize;
+    cd.pixel_size = cam->pixel_size; cd.half_width = cam->half_width; cd.half_height = cam->half_height;
+    if (!affine_rows(cam->inverse, cd.inv, &cd.w33)) return fail(ctx, RTX_E_UNSUPPORTED, "camera transform is not affine");
+    cd.div = !(cd.w33 == 1.0);
+    // origin = inverse * Point(0,0,0)  (camera.rs:66), same arithmetic as the per-pixel transform
+    for (int r = 0; r < 3; r++) {
+        const double* m = cd.inv + r * 4;
+        double v = m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3];
+        cd.origin[r] = cd.div ? v / cd.w33 : v;
+    }
+    RenderParams rp; std::memset(&rp, 0, sizeof rp);
+    rp.max_depth = max_depth; rp.band_first = bands.first; rp.band_stride = bands.stride;
+    rp.n_bands_local = local_bands(cam->vsize, bands);
+    rp.tiles_x = (cam->hsize + RTX_TILE - 1) / RTX_TILE;
+    rp.compact = (flags & RTX_F_BANDS_COMPACT) ? 1 : 0;
+    rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
+
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, RTX_CNT_TOTAL * sizeof(unsigned long long), st));
+    if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+    HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &rp, (uint8_t*)d_rgb, (int32_t*)d_hit, ctx->d_counters,
+                                       (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, st));
+    if (stats) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
+        unsigned long long h[RTX_CNT_TOTAL];
+        HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        std::memset(stats, 0, sizeof *stats);
+        // valid pixels of the rendered bands = primary rays
+        uint64_t prim = 0;
+        for (int b = 0; b < rp.n_bands_local; b++) {
+            int y0 = (bands.first + b * bands.stride) * RTX_TILE;
+            int rows = cam->vsize - y0; if (rows > RTX_TILE) rows = RTX_TILE;
+            if (rows > 0) prim += (uint64_t)rows * cam->hsize;
+        }
+        stats->rays_primary = prim;
+        stats->rays_secondary = h[RTX_CNT_RADIANCE] - prim;
+        stats->rays_shadow = h[RTX_CNT_SHADOW];
+        stats->overflow_pixels = h[RTX_CNT_OVERFLOW];
+        for (int i = 0; i < RTX_EV_COUNT; i++) stats->ev[i] = h[RTX_CNT_EV0 + i];
+        stats->kernel_ms = ms;
+        if (stats->overflow_pixels) return fail(ctx, RTX_E_CAPACITY, "bounded CSG list overflowed on the device");
+    }
+    return RTX_OK;
+}
+
+int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+               uint32_t flags, uint8_t* rgb, int32_t* hit, rtx_stats* stats) {
+    if (!ctx || !scene || !cam || !rgb) return RTX_E_INVALID;
+    if (cam->hsize <= 0 || cam->vsize <= 0) return fail(ctx, RTX_E_INVALID, "empty camera");
+    if (bands.first < 0 || bands.stride < 1) return fail(ctx, RTX_E_INVALID, "bad band selection");
+    const bool compact = (flags & RTX_F_BANDS_COMPACT) != 0;
+    const int nb = local_bands(cam->vsize, bands);
+    const size_t rows = compact ? (size_t)nb * RTX_TILE : (size_t)cam->vsize;
+    const size_t npx = rows * cam->hsize;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (npx * 3 > ctx->rgb_cap) {
+        if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+        ctx->d_rgb = nullptr; ctx->rgb_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_rgb, npx * 3));
+        ctx->rgb_cap = npx * 3;
+    }
+    if (hit && npx * 4 > ctx->hit_cap) {
+        if (ctx->d_hit) (void)hipFree(ctx->d_hit);
+        ctx->d_hit = nullptr; ctx->hit_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_hit, npx * 4));
+        ctx->hit_cap = npx * 4;
+    }
+    rtx_stats local;
+    int rc = rtx_render_device(ctx, scene, cam, max_depth, bands, flags, ctx->d_rgb, hit ? ctx->d_hit : nullptr,
+                               nullptr, stats ? stats : &local);
+    if (rc != RTX_OK) return rc;
+    const size_t W = cam->hsize;
+    if (compact || bands.stride == 1) {
+        // contiguous block of rows
+        size_t r0 = compact ? 0 : (size_t)bands.first * RTX_TILE;
+        size_t r1 = compact ? (size_t)nb * RTX_TILE : (size_t)cam->vsize;
+        if (compact) {
+            // the last band may be partial: copy only rows that exist
+            int last_y0 = (bands.first + (nb - 1) * bands.stride) * RTX_TILE;
+            int last_rows = nb > 0 ? cam->vsize - last_y0 : 0; if (last_rows > RTX_TILE) last_rows = RTX_TILE;
+            r1 = nb > 0 ? (size_t)(nb - 1) * RTX_TILE + last_rows : 0;
+        }
+        if (r1 > r0) {
+            HIPCHK(ctx, hipMemcpy(rgb + r0 * W * 3, ctx->d_rgb + r0 * W * 3, (r1 - r0) * W * 3, hipMemcpyDeviceToHost));
+            if (hit) HIPCHK(ctx, hipMemcpy(hit + r0 * W, ctx->d_hit + r0 * W, (r1 - r0) * W * 4, hipMemcpyDeviceToHost));
+        }
+    } else {
+        for (int b = 0; b < nb; b++) {
+            size_t y0 = (size_t)(bands.first + b * bands.stride) * RTX_TILE;
+            size_t y1 = y0 + RTX_TILE; if (y1 > (size_t)cam->vsize) y1 = cam->vsize;
+            HIPCHK(ctx, hipMemcpy(rgb + y0 * W * 3, ctx->d_rgb + y0 * W * 3, (y1 - y0) * W * 3, hipMemcpyDeviceToHost));
+            if (hit) HIPCHK(ctx, hipMemcpy(hit + y0 * W, ctx->d_hit + y0 * W, (y1 - y0) * W * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return RTX_OK;
+}
+
+}  // extern "C"

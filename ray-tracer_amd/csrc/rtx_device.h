@@ -1,0 +1,95 @@
+// rtx_device.h — device-side scene layout shared by the scene compiler
+// (rtx_api.hip) and the kernel (rtx_kernel.hip).
+//
+// The scene graph (object_store.rs / group.rs / csg.rs) is compiled into a linear
+// TRAVERSAL PROGRAM: the nodes in the reference's depth-first visiting order
+// (world.rs:113, group.rs:70, csg.rs:80-81) with explicit BEGIN/MID/END records for
+// containers.  A whole wavefront walks the program together (the op index is
+// wave-uniform, so records are fetched with scalar loads into SGPRs); lanes that
+// failed a container's bounds test sit out until the op index reaches their
+// `resume_at`.  Visiting order == reference order, so "first hit wins ties"
+// reproduces the stable sorts of intersections.rs:53,58 without any list.
+#ifndef RTX_DEVICE_H
+#define RTX_DEVICE_H
+#include <stdint.h>
+
+enum {
+    OPK_SPHERE = 0, OPK_PLANE = 1, OPK_CUBE = 2,     // == RTX_NODE_* for shapes
+    OPK_GROUP_BEGIN = 3, OPK_GROUP_END = 4,
+    OPK_CSG_BEGIN = 5, OPK_CSG_MID = 6, OPK_CSG_END = 7
+};
+enum {
+    OPF_LIST = 1,      // inside a CSG root: hits go to the per-lane list, not the running state
+    OPF_DIV = 2,       // inverse's w33 != 1.0: keep the point division (nalgebra Projective3*Point3)
+    OPF_ROOT = 4       // CSG_BEGIN/CSG_END of a CSG root (a CSG with no CSG ancestor)
+};
+
+// 192 bytes, 64-byte aligned; read through scalar loads (wave-uniform index).
+struct OpRec {
+    int32_t kind;      // OPK_*
+    int32_t level;     // nesting depth: the ray to transform is the local ray of level-1 (0 = world ray)
+    int32_t skip;      // BEGIN ops: index just past the matching END
+    int32_t flags;     // OPF_*
+    int32_t shape;     // shape ops: ShapeIndex; CSG ops: operator
+    int32_t clevel;    // container nesting level inside the CSG root (list mode)
+    int32_t pad0, pad1;
+    double inv[12];    // rows 0..2 of inverse(transform): inv[r*4+c]
+    double w33;        // inverse(3,3)
+    double bounds[6];  // containers: local bounds {min xyz, max xyz}
+    double pad2;
+};
+
+// per ShapeIndex
+struct ShapeRec {
+    int32_t type;        // OPK_SPHERE/PLANE/CUBE
+    int32_t material;
+    int32_t path_begin;  // into path_ops[]: op indices root -> shape (world_to_object chain)
+    int32_t path_len;
+};
+
+struct MaterialRec {     // 208 bytes
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    double a[3], b[3];
+    double pinv[12];     // rows 0..2 of inverse(pattern.transform)
+    double pw33;
+    int32_t kind;
+    int32_t pdiv;        // pw33 != 1.0
+};
+
+struct LightRec { double pos[3]; double intensity[3]; };
+
+struct SceneDev {
+    const OpRec* ops;
+    const ShapeRec* shapes;
+    const int32_t* path_ops;
+    const MaterialRec* materials;
+    const LightRec* lights;
+    int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = LDS ray-stack slots needed
+    int32_t has_csg, has_transparency;
+};
+
+struct CameraDev {
+    int32_t hsize, vsize;
+    double pixel_size, half_width, half_height;
+    double inv[12], w33;      // rows of inverse(camera.transform)
+    double origin[3];         // inverse * Point(0,0,0), identical for every pixel (camera.rs:66)
+    int32_t div, pad;
+};
+
+struct RenderParams {
+    int32_t max_depth;
+    int32_t band_first, band_stride, n_bands_local;   // bands this launch renders
+    int32_t tiles_x;
+    int32_t compact;          // write bands back-to-back
+    int32_t no_early_out;
+    int32_t pad;
+};
+
+// counters[]: 0 radiance rays, 1 shadow rays, 2 overflow pixels, 3.. events
+#define RTX_CNT_RADIANCE 0
+#define RTX_CNT_SHADOW 1
+#define RTX_CNT_OVERFLOW 2
+#define RTX_CNT_EV0 3
+#define RTX_CNT_TOTAL (3 + 16)
+
+#endif

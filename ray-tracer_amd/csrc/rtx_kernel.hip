@@ -1,0 +1,665 @@
+// rtx_kernel.hip — trace_shade: the MI355X (gfx950, wave64) kernel behind rtx_render().
+//
+// One thread per pixel, one wavefront per 8x8 tile (block = 64 threads, no barriers).
+// Replaces the body of the pixel loop of Camera::render (camera.rs:45-51):
+//   ray_for_pixel (camera.rs:56-69) -> World::color_at (world.rs:100-109)
+//   -> intersect / hit (world.rs:111-118, intersections.rs:37-39)
+//   -> PreparedComputations (world.rs:225-296) -> shade_hit (world.rs:127-149)
+//   -> is_shadowed (:195-207), lighting (material.rs:54-81), patterns (patterns.rs:84-160),
+//      reflected/refracted_color (:151-193), schlick (:304-323) -> Color::to_rgb (color.rs:40-48).
+//
+// Design:
+//  * all arithmetic f64 in the reference's operation order; built with -ffp-contract=off
+//    (Rust never fuses a*b+c), IEEE division and sqrt.
+//  * the scene is a linear traversal program walked wave-uniformly (rtx_device.h); node records
+//    arrive through scalar loads and are consumed as SGPR operands of the f64 VALU ops.
+//  * no hit lists outside CSG subtrees: closest hit / shadow / refractive containers are O(1)
+//    running state that is provably equal to the reference's sorted Vec.
+//    Under a CSG root a bounded per-lane list (RTX_MAX_CSG_ENTRIES) is built, stably merged and
+//    filtered exactly like csg.rs:73-136.
+//  * recursion (world.rs:160,190) becomes a per-lane state machine with an explicit post-order
+//    frame stack of max_depth frames; every lane always traces *some* ray (radiance or shadow)
+//    in the shared traversal, so reflection/refraction divergence does not idle lanes.
+//  * local rays of enclosing containers live in an LDS stack (n_levels x 6 x 64 doubles).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+
+#define DI __device__ __forceinline__
+#define AS4 __attribute__((address_space(4)))
+
+namespace {
+
+struct V3 { double x, y, z; };
+DI V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DI V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DI V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+DI V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+DI V3 neg(V3 a) { return {-a.x, -a.y, -a.z}; }
+// nalgebra 3-vector dot: (a0*b0 + a1*b1) + a2*b2
+DI double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DI double norm3(V3 a) { return __builtin_sqrt(dot3(a, a)); }
+DI V3 normalize3(V3 a) { return a / norm3(a); }            // unscale: component-wise division
+DI V3 reflect3(V3 v, V3 n) { return v - n * 2.0 * dot3(v, n); }   // geometry.rs:49-51
+
+#define INF __builtin_inf()
+
+// Projective3 * Point3 with an affine matrix: (M3x3 p + t) / w33   (rows m[r*4+c])
+template <typename P>
+DI V3 xf_point(P m, double w33, bool div, V3 p) {
+    V3 r;
+    r.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    r.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    r.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    if (div) r = r / w33;
+    return r;
+}
+template <typename P>
+DI V3 xf_vector(P m, V3 v) {
+    V3 r;
+    r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z;
+    r.y = m[4] * v.x + m[5] * v.y + m[6] * v.z;
+    r.z = m[8] * v.x + m[9] * v.y + m[10] * v.z;
+    return r;
+}
+// transpose(inverse 3x3) * n   (object_store.rs:332-337)
+template <typename P>
+DI V3 xf_normal(P m, V3 n) {
+    V3 r;
+    r.x = m[0] * n.x + m[4] * n.y + m[8] * n.z;
+    r.y = m[1] * n.x + m[5] * n.y + m[9] * n.z;
+    r.z = m[2] * n.x + m[6] * n.y + m[10] * n.z;
+    return r;
+}
+
+// bounds.rs:77-94 / cube.rs:54-71
+DI void check_axis(double origin, double direction, double mn, double mx, double& tmin, double& tmax) {
+    double tmin_n = mn - origin;
+    double tmax_n = mx - origin;
+    double a, b;
+    if (__builtin_fabs(direction) >= 1e-12) {
+        a = tmin_n / direction;
+        b = tmax_n / direction;
+    } else {
+        a = tmin_n * INF;
+        b = tmax_n * INF;
+    }
+    if (a > b) { double t = a; a = b; b = t; }
+    tmin = a; tmax = b;
+}
+// slab test shared by Bounds::intersects (bounds.rs:42-54) and the cube (cube.rs:18-31)
+DI bool slabs(V3 o, V3 d, double x0, double y0, double z0, double x1, double y1, double z1,
+              double& tmin, double& tmax) {
+    double xa, xb, ya, yb, za, zb;
+    check_axis(o.x, d.x, x0, x1, xa, xb);
+    check_axis(o.y, d.y, y0, y1, ya, yb);
+    check_axis(o.z, d.z, z0, z1, za, zb);
+    tmin = __builtin_fmax(__builtin_fmax(xa, ya), za);     // f64::max ignores NaN == fmax
+    tmax = __builtin_fmin(__builtin_fmin(xb, yb), zb);
+    return tmin <= tmax;
+}
+
+// low bit of `floor(v) as i64` (saturating cast, NaN -> 0): patterns.rs:98,115,130
+DI int floor_parity(double v) {
+    double f = __builtin_floor(v);
+    if (!(f == f)) return 0;
+    if (f >= 9223372036854775808.0) return 1;     // i64::MAX is odd
+    if (f <= -9223372036854775808.0) return 0;    // i64::MIN is even
+    double h = f * 0.5;
+    return (h == __builtin_floor(h)) ? 0 : 1;
+}
+
+DI uint8_t quantise(double x) {                   // color.rs:32-43
+    if (x < 0.0) x = 0.0; else if (x > 1.0) x = 1.0;      // f64::clamp, NaN stays
+    double v = __builtin_round(x * 255.0);        // half away from zero
+    if (!(v == v)) return 0;
+    if (v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)(int)v;
+}
+
+DI int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+DI unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct Frame {           // one pending shade_hit (world.rs:127-149) waiting for its children
+    double sr, sg, sb;   // surface
+    double ar, ag, ab;   // reflected (already * reflective)
+    double ox, oy, oz, dx, dy, dz;   // refraction ray (world.rs:186-188)
+    double reflectance;
+    int32_t shape;
+    int32_t flags;       // 1: refraction ray pending, 2: waiting for the refracted child, 4: schlick mix
+    int32_t remaining;   // the `remaining` this shade_hit was called with
+};
+
+enum { MODE_DONE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
+const uint32_t LBIT = 0x80000000u;
+
+}  // namespace
+
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
+                                                         uint8_t* __restrict__ rgb,
+                                                         int32_t* __restrict__ hit_out,
+                                                         unsigned long long* __restrict__ counters) {
+    extern __shared__ double lds_rays[];   // [level][6][64]
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx = tile % rp.tiles_x, bl = tile / rp.tiles_x;
+    const int band = rp.band_first + bl * rp.band_stride;
+    const int px = tx * RTX_TILE + (lane & 7);
+    const int py = band * RTX_TILE + (lane >> 3);
+    const bool valid = px < cam.hsize && py < cam.vsize;
+
+    const AS4 OpRec* ops = (const AS4 OpRec*)(uintptr_t)sc.ops;
+    const int n_ops = sc.n_ops;
+    const int n_lights = sc.n_lights;
+
+    // ---- per-lane counters
+    unsigned n_radiance = 0, n_shadow = 0, overflow = 0;
+    unsigned ev[12];
+    if (COUNT) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) ev[i] = 0;
+    }
+#define EV(e, n) do { if (COUNT) ev[e] += (n); } while (0)
+
+    // ---- Camera::ray_for_pixel (camera.rs:56-69)
+    V3 ro, rd;
+    {
+        double xoffset = ((double)px + 0.5) * cam.pixel_size;
+        double yoffset = ((double)py + 0.5) * cam.pixel_size;
+        double world_x = cam.half_width - xoffset;
+        double world_y = cam.half_height - yoffset;
+        V3 pixel = xf_point(cam.inv, cam.w33, cam.div != 0, V3{world_x, world_y, -1.0});
+        ro = V3{cam.origin[0], cam.origin[1], cam.origin[2]};
+        rd = normalize3(pixel - ro);
+    }
+
+    int mode = valid ? MODE_RADIANCE : MODE_DONE;
+    int remaining = rp.max_depth;
+    int sp = 0;
+    Frame frames[RTX_MAX_DEPTH];
+    bool primary = true;
+    int primary_id = -1;
+    double resr = 0.0, resg = 0.0, resb = 0.0;
+
+    // hit context, live across the shadow traces of one shade_hit
+    V3 hp = {0, 0, 0}, eyev = {0, 0, 0}, nv = {0, 0, 0};
+    double n1 = 1.0, n2 = 1.0;
+    int hshape = -1;
+    double sr = 0.0, sg = 0.0, sb = 0.0;       // surface accumulator
+    double pcr = 0.0, pcg = 0.0, pcb = 0.0;    // pattern colour at the hit
+    int light_k = 0;
+    double shadow_dist = 0.0;
+
+    // CSG hit list (per lane)
+    double lt[CSG ? RTX_MAX_CSG_ENTRIES : 1];
+    uint32_t ls[CSG ? RTX_MAX_CSG_ENTRIES : 1];
+
+    while (__any(mode != MODE_DONE)) {
+        // ================================================================= TRACE
+        // World::intersect (world.rs:111-118) for every lane's current ray.
+        if (mode == MODE_RADIANCE) n_radiance++;
+        else if (mode == MODE_SHADOW) n_shadow++;
+
+        bool have = false; double best_t = 0.0; int best_shape = -1; bool best_inside = false;
+        double c1t = -INF, c2t = -INF; int c1s = -1, c2s = -1;     // refractive containers (§9.3)
+        int resume_at = (mode != MODE_DONE) ? 0 : n_ops;
+        int cnt = 0;                      // CSG list length
+        uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
+        const bool is_shadow = mode == MODE_SHADOW;
+
+        // feed the hits of one shape (sorted, k <= 2) into the running state
+        auto feed = [&](int k, double t0, double t1, int shape) {
+            if (k == 0) return;
+            const bool nn0 = t0 >= 0.0;
+            if (nn0) {
+                if (!have || t0 < best_t) { have = true; best_t = t0; best_shape = shape; best_inside = false; }
+            } else {
+                if (k == 2 && t1 >= 0.0) {
+                    if (!have || t1 < best_t) { have = true; best_t = t1; best_shape = shape; best_inside = true; }
+                }
+                // exactly one negative entry -> the shape is an open container behind the origin
+                if (k == 1 || t1 >= 0.0) {
+                    if (t0 >= c1t) { c2t = c1t; c2s = c1s; c1t = t0; c1s = shape; }
+                    else if (t0 >= c2t) { c2t = t0; c2s = shape; }
+                }
+            }
+        };
+
+        int cur = 0;
+        while (cur < n_ops) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            const bool active = cur >= resume_at;
+            if (!__any(active)) {
+                cur = wave_min(resume_at);
+                continue;
+            }
+            const AS4 OpRec* op = ops + cur;
+            const int kind = op->kind;
+            const int level = op->level;
+            const int flags = op->flags;
+            int next = cur + 1;
+
+            if (kind <= OPK_CSG_BEGIN && kind != OPK_GROUP_END) {
+                // ---- ObjectStore::intersect (object_store.rs:243-260): ray into node space
+                V3 po, pd;
+                if (level == 0) { po = ro; pd = rd; }
+                else {
+                    const double* s = lds_rays + (level - 1) * 384 + lane;
+                    po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
+                }
+                V3 lo = xf_point(op->inv, op->w33, (flags & OPF_DIV) != 0, po);
+                V3 ld = xf_vector(op->inv, pd);
+                if (active) EV(RTX_EV_XFORM, 1);
+
+                if (kind <= OPK_CUBE) {
+                    int k = 0; double t0 = 0.0, t1 = 0.0;
+                    if (kind == OPK_SPHERE) {                 // sphere.rs:16-32
+                        if (active) EV(RTX_EV_SPHERE, 1);
+                        double a = dot3(ld, ld);
+                        double b = 2.0 * dot3(ld, lo);
+                        double c = dot3(lo, lo) - 1.0;
+                        double disc = b * b - 4.0 * a * c;
+                        if (!(disc < 0.0)) {
+                            double sq = __builtin_sqrt(disc);
+                            t0 = (-b - sq) / (2.0 * a);
+                            t1 = (-b + sq) / (2.0 * a);
+                            k = 2;
+                        }
+                    } else if (kind == OPK_PLANE) {           // plane.rs:16-23
+                        if (active) EV(RTX_EV_PLANE, 1);
+                        if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
+                    } else {                                  // cube.rs:18-31
+                        if (active) EV(RTX_EV_CUBE, 1);
+                        if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
+                    }
+                    if (active) {
+                        const int shape = op->shape;
+                        if (CSG && (flags & OPF_LIST)) {
+                            if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
+                            if (k >= 1) { lt[cnt] = t0; ls[cnt] = (uint32_t)shape; cnt++; }
+                            if (k == 2) { lt[cnt] = t1; ls[cnt] = (uint32_t)shape; cnt++; }
+                        } else {
+                            feed(k, t0, t1, shape);
+                            // is_shadowed (world.rs:203-206): any 0 <= t < distance decides
+                            if (is_shadow && !rp.no_early_out && have && best_t < shadow_dist) resume_at = n_ops;
+                        }
+                    }
+                } else {
+                    // ---- Groups::local_intersect (group.rs:64-75) / CSGs::local_intersect (csg.rs:73-78)
+                    if (active) EV(RTX_EV_BOUNDS, 1);
+                    double tmin, tmax;
+                    bool pass = slabs(lo, ld, op->bounds[0], op->bounds[1], op->bounds[2],
+                                      op->bounds[3], op->bounds[4], op->bounds[5], tmin, tmax);
+                    pass = pass && active;
+                    if (active && !pass) resume_at = op->skip;
+                    if (!__any(pass)) {
+                        next = op->skip;
+                    } else {
+                        double* s = lds_rays + level * 384 + lane;
+                        if (pass) {
+                            s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
+                            s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
+                            if (CSG && (flags & OPF_LIST)) {
+                                const int sh = op->clevel * 8;
+                                starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
+                            }
+                        }
+                    }
+                }
+            } else if (CSG && (flags & OPF_LIST) && active) {
+                const int sh = op->clevel * 8;
+                if (kind == OPK_CSG_MID) {
+                    mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
+                } else {
+                    const int s0 = (int)((starts >> sh) & 0xff);
+                    if (kind == OPK_CSG_END) {
+                        // csg.rs:83-90: left_shapes membership == "came from the left child"
+                        const int m0 = (int)((mids >> sh) & 0xff);
+                        for (int i = s0; i < cnt; i++) ls[i] = (i < m0) ? (ls[i] | LBIT) : (ls[i] & ~LBIT);
+                    }
+                    // stable sort of the concatenated child lists (intersections.rs:56-59)
+                    for (int i = s0 + 1; i < cnt; i++) {
+                        double t = lt[i]; uint32_t id = ls[i];
+                        int j = i - 1;
+                        while (j >= s0 && lt[j] > t) { lt[j + 1] = lt[j]; ls[j + 1] = ls[j]; j--; }
+                        lt[j + 1] = t; ls[j + 1] = id;
+                    }
+                    if (kind == OPK_CSG_END) {
+                        // filter_intersections (csg.rs:94-121)
+                        const int cop = op->shape;
+                        bool inl = false, inr = false;
+                        int out = s0;
+                        for (int i = s0; i < cnt; i++) {
+                            EV(RTX_EV_CSG_ENTRIES, 1);
+                            const double t = lt[i]; const uint32_t id = ls[i];
+                            const bool lhit = (id & LBIT) != 0;
+                            bool allowed;                     // csg.rs:123-136
+                            if (cop == RTX_CSG_UNION) allowed = (lhit && !inr) || (!lhit && !inl);
+                            else if (cop == RTX_CSG_INTERSECTION) allowed = (lhit && inr) || (!lhit && inl);
+                            else allowed = (lhit && !inr) || (!lhit && inl);
+                            if (allowed) {
+                                // Intersections::add_intersection (intersections.rs:41-47): binary search insert
+                                int size = out - s0, left = 0, right = size, pos = -1;
+                                while (left < right) {
+                                    int mid = left + size / 2;
+                                    double tm = lt[s0 + mid];
+                                    if (tm < t) left = mid + 1;
+                                    else if (tm > t) right = mid;
+                                    else { pos = mid; break; }
+                                    size = right - left;
+                                }
+                                if (pos < 0) pos = left;
+                                for (int j = out; j > s0 + pos; j--) { lt[j] = lt[j - 1]; ls[j] = ls[j - 1]; }
+                                lt[s0 + pos] = t; ls[s0 + pos] = id;
+                                out++;
+                            }
+                            if (lhit) inl = !inl; else inr = !inr;
+                        }
+                        cnt = out;
+                        if (flags & OPF_ROOT) {
+                            // hand the filtered list of this CSG root to the running state
+                            for (int i = 0; i < cnt; i++) {
+                                const double t = lt[i]; const int shape = (int)(ls[i] & ~LBIT);
+                                int negs = 0;
+                                for (int j = 0; j < cnt; j++)
+                                    if ((int)(ls[j] & ~LBIT) == shape && !(lt[j] >= 0.0)) negs++;
+                                if (t >= 0.0) {
+                                    if (!have || t < best_t) { have = true; best_t = t; best_shape = shape; best_inside = (negs == 1); }
+                                    break;      // later entries are larger
+                                } else if (negs == 1) {
+                                    if (t >= c1t) { c2t = c1t; c2s = c1s; c1t = t; c1s = shape; }
+                                    else if (t >= c2t) { c2t = t; c2s = shape; }
+                                }
+                            }
+                            cnt = 0;
+                            if (is_shadow && !rp.no_early_out && have && best_t < shadow_dist) resume_at = n_ops;
+                        }
+                    }
+                }
+            }
+            cur = next;
+        }
+
+        // ================================================================= SHADE
+        bool returning = false;                 // lane has a finished colour to hand to its parent frame
+        double rr = 0.0, rg = 0.0, rb = 0.0;
+        bool lights_done = false;
+
+        if (mode == MODE_RADIANCE) {
+            if (primary) { primary_id = have ? best_shape : -1; primary = false; }
+            if (!have) {                        // world.rs:107
+                returning = true;
+            } else {
+                // ---- PreparedComputations::new (world.rs:225-256)
+                EV(RTX_EV_HIT, 1);
+                hshape = best_shape;
+                hp = ro + rd * best_t;          // rays.rs:17-19 (t * direction is commutative)
+                eyev = neg(rd);
+                const ShapeRec srec = sc.shapes[hshape];
+                EV(RTX_EV_LEVELS, srec.path_len);
+                // world_to_object (object_store.rs:309-320): root -> shape
+                V3 objp = hp;
+                for (int i = 0; i < srec.path_len; i++) {
+                    const OpRec* xo = sc.ops + sc.path_ops[srec.path_begin + i];
+                    objp = xf_point(xo->inv, xo->w33, (xo->flags & OPF_DIV) != 0, objp);
+                }
+                V3 ln;
+                if (srec.type == OPK_SPHERE) ln = objp;                          // sphere.rs:34-36
+                else if (srec.type == OPK_PLANE) ln = V3{0.0, 1.0, 0.0};          // plane.rs:25-27
+                else {                                                            // cube.rs:33-47
+                    double ax = __builtin_fabs(objp.x), ay = __builtin_fabs(objp.y), az = __builtin_fabs(objp.z);
+                    double maxc = __builtin_fmax(__builtin_fmax(ax, ay), az);
+                    if (maxc == ax) ln = V3{objp.x, 0.0, 0.0};
+                    else if (maxc == ay) ln = V3{0.0, objp.y, 0.0};
+                    else ln = V3{0.0, 0.0, objp.z};
+                }
+                // normal_to_world (object_store.rs:331-349): shape -> root, normalised per level
+                for (int i = srec.path_len - 1; i >= 0; i--) {
+                    const OpRec* xo = sc.ops + sc.path_ops[srec.path_begin + i];
+                    ln = normalize3(xf_normal(xo->inv, ln));
+                }
+                nv = ln;
+                if (dot3(nv, eyev) < 0.0) nv = neg(nv);                           // world.rs:232-237
+                // get_refractive_indices_at (world.rs:258-296) from the running state (§9.3)
+                {
+                    const MaterialRec* mats = sc.materials;
+                    n1 = (c1s >= 0) ? mats[sc.shapes[c1s].material].refractive_index : 1.0;
+                    if (c1s >= 0 && best_inside) {
+                        const int s2 = (hshape == c1s) ? c2s : c1s;
+                        n2 = (s2 >= 0) ? mats[sc.shapes[s2].material].refractive_index : 1.0;
+                    } else {
+                        n2 = mats[srec.material].refractive_index;
+                    }
+                }
+                // pattern colour (object_store.rs:293-299); same point for every light
+                {
+                    const MaterialRec* m = sc.materials + srec.material;
+                    const int pk = m->kind;
+                    V3 a = {m->a[0], m->a[1], m->a[2]};
+                    if (pk == RTX_PAT_PLAIN) { pcr = a.x; pcg = a.y; pcb = a.z; }
+                    else {
+                        V3 pp = xf_point(m->pinv, m->pw33, m->pdiv != 0, objp);
+                        V3 b = {m->b[0], m->b[1], m->b[2]};
+                        if (pk == RTX_PAT_TEST) { pcr = pp.x; pcg = pp.y; pcb = pp.z; }
+                        else if (pk == RTX_PAT_GRADIENT) {                         // patterns.rs:144-151
+                            double fr = pp.x - __builtin_floor(pp.x);
+                            pcr = a.x + (b.x - a.x) * fr; pcg = a.y + (b.y - a.y) * fr; pcb = a.z + (b.z - a.z) * fr;
+                        } else {
+                            int odd;
+                            if (pk == RTX_PAT_STRIPES) odd = floor_parity(pp.x);                                    // :96-104
+                            else if (pk == RTX_PAT_RINGS) odd = floor_parity(__builtin_sqrt(pp.x * pp.x + pp.z * pp.z));   // :112-121
+                            else odd = floor_parity(pp.x) ^ floor_parity(pp.y) ^ floor_parity(pp.z);                // :128-136
+                            V3 c = odd ? b : a;
+                            pcr = c.x; pcg = c.y; pcb = c.z;
+                        }
+                    }
+                }
+                sr = 0.0; sg = 0.0; sb = 0.0;    // Sum::sum folds from black (color.rs:69-73)
+                light_k = 0;
+                if (n_lights == 0) lights_done = true;
+            }
+        } else if (mode == MODE_SHADOW) {
+            // ---- lighting for light_k (material.rs:54-81) with the shadow answer of this trace
+            const bool in_shadow = have && best_t < shadow_dist;
+            EV(RTX_EV_LIGHT, 1);
+            const LightRec* L = sc.lights + light_k;
+            const MaterialRec* m = sc.materials + sc.shapes[hshape].material;
+            const double ir = L->intensity[0], ig = L->intensity[1], ib = L->intensity[2];
+            const double er = pcr * ir, eg = pcg * ig, eb = pcb * ib;             // effective_color
+            V3 lightv = normalize3(V3{L->pos[0], L->pos[1], L->pos[2]} - hp);
+            const double amb = m->ambient;
+            double cr = er * amb, cg = eg * amb, cb = eb * amb;                   // ambient
+            double dr = 0.0, dg = 0.0, db = 0.0, spr = 0.0, spg = 0.0, spb = 0.0;
+            const double ldn = dot3(lightv, nv);
+            if (!(in_shadow || ldn < 0.0)) {
+                const double dif = m->diffuse;
+                dr = er * dif * ldn; dg = eg * dif * ldn; db = eb * dif * ldn;
+                V3 rv = reflect3(neg(lightv), nv);
+                const double rde = dot3(rv, eyev);
+                if (!(rde <= 0.0)) {
+                    EV(RTX_EV_POW, 1);
+                    const double factor = pow(rde, m->shininess);
+                    const double spec = m->specular;
+                    spr = ir * spec * factor; spg = ig * spec * factor; spb = ib * spec * factor;
+                }
+            }
+            cr = cr + dr + spr; cg = cg + dg + spg; cb = cb + db + spb;           // ambient + diffuse + specular
+            sr = sr + cr; sg = sg + cg; sb = sb + cb;
+            light_k++;
+            if (light_k >= n_lights) lights_done = true;
+        }
+
+        if (mode != MODE_DONE && !returning && !lights_done) {
+            // ---- is_shadowed (world.rs:195-207): next shadow ray, from over_point
+            const LightRec* L = sc.lights + light_k;
+            V3 over = hp + nv * 1e-10;                                            // world.rs:238-239
+            V3 v = V3{L->pos[0], L->pos[1], L->pos[2]} - over;
+            shadow_dist = norm3(v);
+            ro = over; rd = v / shadow_dist;                                      // normalize() recomputes the same norm
+            mode = MODE_SHADOW;
+        }
+
+        if (lights_done) {
+            // ---- rest of shade_hit (world.rs:138-148): decide the children
+            const MaterialRec* m = sc.materials + sc.shapes[hshape].material;
+            const double refl = m->reflective, transp = m->transparency;
+            const bool do_refl = remaining != 0 && !(refl == 0.0);                // world.rs:155
+            bool do_refr = false;
+            V3 fo = {0, 0, 0}, fd = {0, 0, 0};
+            if (remaining != 0 && !(transp == 0.0)) {                             // world.rs:167-170
+                EV(RTX_EV_REFR, 1);
+                const double n_ratio = n1 / n2;
+                const double cos_i = dot3(eyev, nv);
+                const double sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
+                if (!(sin2_t > 1.0)) {
+                    const double cos_t = __builtin_sqrt(1.0 - sin2_t);
+                    fd = nv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+                    fo = hp - nv * 1e-10;                                         // under_point
+                    do_refr = true;
+                }
+            }
+            const bool both = refl > 0.0 && transp > 0.0;
+            double R = 0.0;
+            if (both) {                                                           // schlick (world.rs:304-323)
+                EV(RTX_EV_SCHLICK, 1);
+                double cosv = dot3(eyev, nv);
+                bool tir = false;
+                if (n1 > n2) {
+                    const double n = n1 / n2;
+                    const double s2 = n * n * (1.0 - cosv * cosv);
+                    if (s2 > 1.0) tir = true;
+                    else cosv = __builtin_sqrt(1.0 - s2);
+                }
+                if (tir) R = 1.0;
+                else {
+                    const double q = (n1 - n2) / (n1 + n2);
+                    const double r0 = q * q;
+                    const double x = 1.0 - cosv;
+                    const double x2 = x * x;
+                    R = r0 + (1.0 - r0) * (x * (x2 * x2));
+                }
+            }
+            if (!do_refl && !do_refr) {
+                if (both) { rr = sr + 0.0 * R + 0.0 * (1.0 - R); rg = sg + 0.0 * R + 0.0 * (1.0 - R); rb = sb + 0.0 * R + 0.0 * (1.0 - R); }
+                else { rr = sr + 0.0 + 0.0; rg = sg + 0.0 + 0.0; rb = sb + 0.0 + 0.0; }
+                returning = true;
+            } else {
+                Frame& f = frames[sp];
+                f.sr = sr; f.sg = sg; f.sb = sb;
+                f.ar = 0.0; f.ag = 0.0; f.ab = 0.0;
+                f.ox = fo.x; f.oy = fo.y; f.oz = fo.z; f.dx = fd.x; f.dy = fd.y; f.dz = fd.z;
+                f.reflectance = R;
+                f.shape = hshape;
+                f.remaining = remaining;
+                if (do_refl) {
+                    f.flags = (do_refr ? 1 : 0) | (both ? 4 : 0);
+                    V3 over = hp + nv * 1e-10;
+                    ro = over; rd = reflect3(neg(eyev), nv);                      // reflectv (world.rs:251)
+                } else {
+                    f.flags = 2 | (both ? 4 : 0);
+                    ro = fo; rd = fd;
+                }
+                sp++;
+                remaining = remaining - 1;
+                mode = MODE_RADIANCE;
+            }
+        }
+
+        // ---- unwind: hand finished colours to the waiting frames (post-order)
+        while (returning) {
+            if (sp == 0) {
+                resr = rr; resg = rg; resb = rb;
+                mode = MODE_DONE;
+                returning = false;
+            } else {
+                Frame& f = frames[sp - 1];
+                const MaterialRec* m = sc.materials + sc.shapes[f.shape].material;
+                if (!(f.flags & 2)) {
+                    // reflected child finished (world.rs:160-162)
+                    const double refl = m->reflective;
+                    f.ar = rr * refl; f.ag = rg * refl; f.ab = rb * refl;
+                    if (f.flags & 1) {
+                        f.flags |= 2;
+                        ro = V3{f.ox, f.oy, f.oz}; rd = V3{f.dx, f.dy, f.dz};
+                        remaining = f.remaining - 1;
+                        mode = MODE_RADIANCE;
+                        returning = false;
+                        continue;
+                    }
+                    rr = 0.0; rg = 0.0; rb = 0.0;        // refracted = black
+                } else {
+                    // refracted child finished (world.rs:190-192)
+                    const double transp = m->transparency;
+                    rr = rr * transp; rg = rg * transp; rb = rb * transp;
+                }
+                // combine (world.rs:141-148)
+                if (f.flags & 4) {
+                    const double R = f.reflectance;
+                    rr = f.sr + f.ar * R + rr * (1.0 - R);
+                    rg = f.sg + f.ag * R + rg * (1.0 - R);
+                    rb = f.sb + f.ab * R + rb * (1.0 - R);
+                } else {
+                    rr = f.sr + f.ar + rr; rg = f.sg + f.ag + rg; rb = f.sb + f.ab + rb;
+                }
+                sp--;
+            }
+        }
+    }
+
+    // ---- Canvas::write_pixel + Color::to_rgb (canvas.rs:31-33, color.rs:40-48)
+    if (valid) {
+        const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : py;
+        const size_t idx = (size_t)row * cam.hsize + px;
+        rgb[idx * 3 + 0] = quantise(resr);
+        rgb[idx * 3 + 1] = quantise(resg);
+        rgb[idx * 3 + 2] = quantise(resb);
+        if (hit_out) hit_out[idx] = primary_id;
+    }
+
+    // ---- ray / event counters: one atomic per wave per counter
+    unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow);
+    if (lane == 0) {
+        atomicAdd(&counters[RTX_CNT_RADIANCE], (unsigned long long)t0);
+        atomicAdd(&counters[RTX_CNT_SHADOW], (unsigned long long)t1);
+        if (t2) atomicAdd(&counters[RTX_CNT_OVERFLOW], (unsigned long long)t2);
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            unsigned s = wave_sum(ev[i]);
+            if (lane == 0 && s) atomicAdd(&counters[RTX_CNT_EV0 + i], (unsigned long long)s);
+        }
+    }
+#undef EV
+}
+
+// ---------------------------------------------------------------- launcher (called by rtx_api.hip)
+extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
+                                             uint8_t* rgb, int32_t* hit, unsigned long long* counters,
+                                             int count_events, hipStream_t stream) {
+    const int blocks = rp->tiles_x * rp->n_bands_local;
+    if (blocks <= 0) return hipSuccess;
+    const size_t lds = (size_t)sc->n_levels * 6 * 64 * sizeof(double);
+    dim3 grid(blocks), block(64);
+    const bool csg = sc->has_csg != 0;
+    if (count_events) {
+        if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+        else     hipLaunchKernelGGL((trace_shade_kernel<false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+    } else {
+        if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+        else     hipLaunchKernelGGL((trace_shade_kernel<false, false>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,62 @@
+// rt_frontend.cpp — rtxh_load_yaml / rtxh_write_png / rtxh_render_file: the C entry points for
+// yaml.rs:22-73, canvas.rs:39-53 and main.rs:20-28.
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "rt_world.h"
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char* rtxh_last_error(void) { return g_err.c_str(); }
+
+int rtxh_load_yaml(const char* text, rtxh_world** world_out, rtxh_camera* cameras_out, int max_cameras,
+                   int* n_cameras_out) {
+    if (!text || !world_out) return RTX_E_INVALID;
+    *world_out = nullptr;
+    rtxh_world* w = new rtxh_world();
+    std::vector<rtxh_camera> cams;
+    if (!rth::load_yaml(text, w->w, cams, g_err)) { delete w; return RTX_E_INVALID; }
+    if (n_cameras_out) *n_cameras_out = (int)cams.size();
+    for (int i = 0; i < (int)cams.size() && i < max_cameras && cameras_out; i++) cameras_out[i] = cams[i];
+    *world_out = w;
+    return RTX_OK;
+}
+
+int rtxh_write_png(const char* path, const uint8_t* rgb, int width, int height) {
+    if (!path) return RTX_E_INVALID;
+    return rth::write_png(path, rgb, width, height, g_err) ? RTX_OK : RTX_E_INVALID;
+}
+
+int rtxh_render_file(const char* yaml_path, const char* out_dir, int device) {
+    if (!yaml_path) return RTX_E_INVALID;
+    std::ifstream in(yaml_path, std::ios::binary);
+    if (!in) { g_err = std::string("cannot read ") + yaml_path; return RTX_E_INVALID; }   // main.rs:21 unwrap()
+    std::stringstream ss; ss << in.rdbuf();
+    rtxh_world* w = nullptr; rtxh_camera cam; int ncam = 0;
+    int rc = rtxh_load_yaml(ss.str().c_str(), &w, &cam, 1, &ncam);
+    if (rc != RTX_OK) return rc;
+    if (ncam < 1) { g_err = "scene has no camera"; rtxh_world_free(w); return RTX_E_INVALID; }   // cameras[0] (main.rs:24)
+    rtx_ctx* ctx = nullptr;
+    rc = rtx_init(device, &ctx);
+    if (rc != RTX_OK) { g_err = "rtx_init failed: no usable HIP device"; rtxh_world_free(w); return rc; }
+    std::vector<uint8_t> rgb((size_t)cam.hsize * cam.vsize * 3);
+    rc = rtxh_render(ctx, w, &cam, 5 /* camera.rs:42 */, 0, rgb.data(), nullptr, nullptr);
+    if (rc != RTX_OK) g_err = rtx_last_error(ctx);
+    rtx_shutdown(ctx); rtxh_world_free(w);
+    if (rc != RTX_OK) return rc;
+    // main.rs:25-26: file_name() with extension png, in the current (or given) directory
+    std::string p(yaml_path);
+    size_t sl = p.find_last_of('/');
+    std::string name = sl == std::string::npos ? p : p.substr(sl + 1);
+    size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) name = name.substr(0, dot);
+    std::string out = (out_dir && *out_dir) ? std::string(out_dir) + "/" + name + ".png" : name + ".png";
+    return rtxh_write_png(out.c_str(), rgb.data(), cam.hsize, cam.vsize);
+}
+
+}  // extern "C"

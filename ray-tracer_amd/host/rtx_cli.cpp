@@ -1,0 +1,17 @@
+// rtx_cli.cpp — `rtx <scene.yaml>`: the reference's CLI (main.rs:11-28) on the MI355X path.
+#include <cstdio>
+
+#include "../../include/rtx_host.h"
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::printf("Need to provide filename of scene description as argument\n");   // main.rs:16
+        return 0;
+    }
+    int rc = rtxh_render_file(argv[1], nullptr, 0);
+    if (rc != RTX_OK) {
+        std::fprintf(stderr, "rtx: %s (%s)\n", rtx_strerror(rc), rtxh_last_error());
+        return 1;
+    }
+    return 0;
+}
