@@ -1,0 +1,41 @@
+"""Algorithmic f64 flops of one frame from event counts (SURVEY.md §8d constants).
+
+One flop per f64 add/sub/mul/div/sqrt/compare/min/max; precomputed inverses assumed.
+The same formula is applied to the oracle's counters (reference-defined work) and to the
+kernel's own counters (work actually executed, fewer shadow-ray visits with early-out).
+"""
+X_RAY = 36        # ray into node space: point 21 + vector 15
+SPH = 30
+PLN = 4
+BOX = 23          # cube test or bounds test
+CSGF = 4          # per merged CSG entry
+HITPREP = 38      # position, flip, over/under, reflect
+NRM = 45          # per hierarchy level: point xform 21 + normal xform 15 + normalize 9
+PAT_LEVEL = 21    # per light and level: world_to_object for the pattern
+PAT_FIXED = 26    # per light: pattern xform 21 + lookup 5
+PHONG = 75
+POW = 1
+SHADOWSETUP = 17
+REFR = 30
+SCHLICK = 20
+RAYGEN = 40
+QUANT = 12
+
+
+def frame_flops(ev, rays_primary, rays_shadow, n_lights):
+    """ev: dict from Stats.events(); returns algorithmic flops."""
+    f = 0
+    f += X_RAY * ev["xform"]
+    f += SPH * ev["sphere"] + PLN * ev["plane"] + BOX * (ev["cube"] + ev["bounds"])
+    f += CSGF * ev["csg_entries"]
+    f += HITPREP * ev["hit"] + NRM * ev["levels"]
+    f += n_lights * (PAT_LEVEL * ev["levels"] + PAT_FIXED * ev["hit"])
+    f += PHONG * ev["light"] + POW * ev["pow"]
+    f += SHADOWSETUP * rays_shadow
+    f += REFR * ev["refr"] + SCHLICK * ev["schlick"]
+    f += (RAYGEN + QUANT) * rays_primary
+    return f
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # 256 CU x 64 lanes x 2 (FMA) x 2.4 GHz (MI355X datasheet FP64 vector)
+FP64_UNFUSED_PEAK_TFLOPS = 39.3    # one flop per lane-issue: the ceiling for parity code (no a*b+c fusion)
