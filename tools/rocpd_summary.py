@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd (.db) result: per-kernel time stats and, if present, PMC counters
+per kernel (averaged over dispatches).  Usage: rocpd_summary.py <results.db> [...]"""
+import sqlite3
+import sys
+
+
+def main():
+    for path in sys.argv[1:]:
+        db = sqlite3.connect(path)
+        cur = db.cursor()
+        print("== %s" % path)
+        rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                           "from kernels group by name order by 3 desc").fetchall()
+        total = sum(r[2] for r in rows) or 1
+        print("%-60s %8s %14s %14s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"))
+        for name, n, tot, avg, mn, mx in rows:
+            print("%-60s %8d %14d %14.0f %14d %14d %6.2f%%" % (name[:60], n, tot, avg, mn, mx, 100.0 * tot / total))
+        try:
+            cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+            if cols:
+                rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+                                   "group by kernel_name, counter_name order by 1, 2").fetchall()
+                if rows:
+                    print("%-60s %-24s %8s %20s %22s" % ("kernel", "counter", "n", "avg/dispatch", "sum"))
+                for k, c, n, avg, sm in rows:
+                    print("%-60s %-24s %8d %20.1f %22.1f" % (k[:60], c, n, avg, sm))
+        except sqlite3.Error as e:
+            print("(no counters: %s)" % e)
+        try:
+            r = cur.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, "
+                            "workgroup_size_x, grid_size_x from kernels group by name").fetchall()
+            for x in r:
+                print("resources:", x)
+        except sqlite3.Error as e:
+            cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+            print("(kernels columns: %s)" % cols)
+
+
+if __name__ == "__main__":
+    main()
