@@ -80,6 +80,7 @@ def main():
     args = ap.parse_args()
 
     import torch
+    import bands as bandlib
     import flops
     import rtx
     import scenes
@@ -110,7 +111,8 @@ def main():
 
     bands = (rank, N)
     rows_local = rtx.LIB.rtx_band_rows(height, rtx.Bands(*bands))
-    rows_pad = ((height + 7) // 8 + N - 1) // N * 8          # equal send counts for the all-gather
+    rows_pad = bandlib.rows_padded(height, N)                  # equal send counts for the all-gather
+    assert rows_local <= rows_pad
     local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(N * rows_pad * width * 3, dtype=torch.uint8, device=dev) if N > 1 else None
     stream = torch.cuda.current_stream().cuda_stream

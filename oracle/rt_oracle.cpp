@@ -152,12 +152,17 @@ M4 translation(V3 v) {                       // geometry.rs:16-23
 M4 scaling(double x, double y, double z) {   // geometry.rs:25-31
     M4 r = identity(); at(r, 0, 0) = x; at(r, 1, 1) = y; at(r, 2, 2) = z; return r;
 }
+// f64::sin_cos() is (sin(), cos()): two separate libm calls.  glibc's sincos() can differ from cos()
+// in the last ulp, so keep the compiler from merging the pair (GCC does at -O2).
+__attribute__((noinline)) double rust_sin(double x) { return std::sin(x); }
+__attribute__((noinline)) double rust_cos(double x) { return std::cos(x); }
+
 // geometry.rs:45-47 -> Rotation3::from_axis_angle (nalgebra) -> to_homogeneous
 M4 rotation_around_axis(V3 u, double angle) {
     if (!(angle != 0.0)) return identity();
     double ux = u.x, uy = u.y, uz = u.z;
     double sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
-    double s = std::sin(angle), c = std::cos(angle);
+    double s = rust_sin(angle), c = rust_cos(angle);
     double k = 1.0 - c;
     M4 r = identity();
     at(r, 0, 0) = sqx + (1.0 - sqx) * c;

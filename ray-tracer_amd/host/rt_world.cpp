@@ -25,12 +25,17 @@ Mat4 mat_translation(double x, double y, double z) {
 Mat4 mat_scaling(double x, double y, double z) {
     Mat4 m = mat_identity(); m(0, 0) = x; m(1, 1) = y; m(2, 2) = z; return m;
 }
+// f64::sin_cos() = (sin(), cos()): two libm calls.  glibc's sincos() differs from cos() in the last
+// ulp for some arguments, so the pair must not be merged into one sincos() call.
+__attribute__((noinline)) static double sin_alone(double x) { return std::sin(x); }
+__attribute__((noinline)) static double cos_alone(double x) { return std::cos(x); }
+
 // Rotation3::from_axis_angle for the unit axis e_axis, embedded in a 4x4 (na::convert)
 Mat4 mat_rotation(int axis, double angle) {
     Mat4 m = mat_identity();
     if (angle == 0.0) return m;                 // simd_ne(zero).if_else(.., identity)
     const double u[3] = {axis == 0 ? 1.0 : 0.0, axis == 1 ? 1.0 : 0.0, axis == 2 ? 1.0 : 0.0};
-    const double sn = std::sin(angle), cs = std::cos(angle), k = 1.0 - cs;
+    const double sn = sin_alone(angle), cs = cos_alone(angle), k = 1.0 - cs;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) {
             if (r == c) {

@@ -1,0 +1,179 @@
+"""CPU-side tests of the product's host code (no GPU, no compute calls on the device):
+the shared library loads and exports every symbol include/*.h declares, the C++ host mirror
+computes the same bits as the oracle for transforms / inverses / bounds, and the C++ YAML
+loader agrees byte for byte with the independent Python loader."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import ora
+import rtx
+import scenes
+import yaml_scene
+from rtapi import CUBE, PLANE, SPHERE, UNION, csg, group, shape
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = set()
+    for h in ("rtx.h", "rtx_host.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"^\s*(?:int|void|int64_t|const char\*|rtxh_world\*)\s+(rtxh?_[a-z_0-9]+)\s*\(", text, flags=re.M))
+    assert declared == set(rtx.RTX_SYMBOLS + rtx.RTXH_SYMBOLS), declared ^ set(rtx.RTX_SYMBOLS + rtx.RTXH_SYMBOLS)
+    for name in declared:
+        assert getattr(rtx.LIB, name) is not None
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(rtx.RtxError) as e:
+        rtx.Context(0)
+    assert e.value.code == rtx.E_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "ray-tracer_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".py", "Makefile")):
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                assert "rt_oracle" not in text and "import ora" not in text, os.path.join(dp, f)
+
+
+def _same(a, b):
+    a, b = np.asarray(list(a), np.float64), np.asarray(list(b), np.float64)
+    if not np.array_equal(a, b, equal_nan=True):
+        return False
+    ok = ~np.isnan(a)                      # NaN payload/sign is not observable by the renderer
+    return np.array_equal(np.signbit(a[ok]), np.signbit(b[ok]))
+
+
+def test_transforms_bit_equal_to_oracle():
+    rng = np.random.default_rng(7)
+    P, O = rtx.API, ora.API
+    for _ in range(200):
+        a = float(rng.uniform(-7, 7))
+        for ax in "xyz":
+            assert _same(getattr(P, "rotation_" + ax)(a), getattr(O, "rotation_" + ax)(a))
+        ops = []
+        for _ in range(int(rng.integers(1, 6))):
+            k = int(rng.integers(0, 5))
+            if k == 0:
+                ops.append(("scale", [float(x) for x in rng.uniform(0.1, 3, 3)]))
+            elif k == 1:
+                ops.append(("translate", [float(x) for x in rng.uniform(-5, 5, 3)]))
+            else:
+                ops.append((["rotate-x", "rotate-y", "rotate-z"][k - 2], float(rng.uniform(-4, 4))))
+        tp, to = P.compose(ops), O.compose(ops)
+        assert _same(tp, to)
+        assert _same(P.inverse(tp), O.inverse(to))
+        f, t, u = rng.uniform(-5, 5, 3), rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 3)
+        assert _same(P.view_transform(f, t, u), O.view_transform(f, t, u))
+    cp, co = P.camera(400, 200, math.pi / 3), O.camera(400, 200, math.pi / 3)
+    assert bytes(cp) == bytes(co)
+    assert P.rotation_x(0.0)[:] == P.identity()[:]
+
+
+def _build_tree(api):
+    w = api.world_new()
+    g1 = w.add_group(api.compose([("rotate-y", 0.7), ("translate", [1, 2, 3])]))
+    g2 = w.add_group(api.compose([("scale", [1, 2, 3]), ("rotate-z", -0.4)]))
+    s1 = w.add_shape(SPHERE, None, api.compose([("scale", [0.5, 0.5, 0.5]), ("rotate-x", 1.1), ("translate", [5, 0, 0])]))
+    s2 = w.add_shape(CUBE, None, api.compose([("rotate-z", 0.3), ("translate", [0, -2, 0.5])]))
+    p = w.add_shape(PLANE, None, api.identity())
+    gp = w.add_group(api.identity())
+    c = w.add_csg(UNION, shape(w.add_shape(SPHERE, None, api.translation(0.5, 0, 0))),
+                  shape(w.add_shape(CUBE, None, api.rotation_y(0.9))), api.scaling(2, 1, 1))
+    w.add_object_to_scene(group(g1)); w.set_group_of(group(g2), g1)
+    w.set_group_of(shape(s1), g2); w.set_group_of(shape(s2), g2); w.set_group_of(csg(c), g1)
+    w.set_group_of(shape(p), gp); w.add_object_to_scene(group(gp))
+    w.build()
+    return w, [group(g1), group(g2), group(gp), csg(c)]
+
+
+def test_bounds_bit_equal_to_oracle_including_the_from_points_quirk():
+    wp, objs = _build_tree(rtx.API)
+    wo, _ = _build_tree(ora.API)
+    for o in objs:
+        assert _same(wp.get_bounds(o), wo.get_bounds(o)), o
+    # a group holding only a plane keeps NaN bounds (inf * 0 corners)
+    assert all(math.isnan(v) for v in wp.get_bounds(objs[2]))
+
+
+@pytest.mark.parametrize("name,kw", [("S1", {}), ("S2", {}), ("S3", dict(levels=2, per_leaf=3)), ("S4", {}), ("S5", {})])
+def test_cpp_yaml_loader_equals_python_loader(name, kw):
+    text = scenes.make(name, **kw)
+    w1, c1 = rtx.load_yaml(text)
+    w2, c2 = yaml_scene.load(text, rtx.API)
+    assert rtx.serialize(w1) == rtx.serialize(w2)
+    assert len(c1) == len(c2) == 1 and bytes(c1[0]) == bytes(c2[0])
+
+
+def test_yaml_expression_quirks():
+    # yaml.rs:466-509: "a op b"; the operator is never cleared, so "1 + 2 3" = 6 and "1 + 2 * 3" is NaN
+    def fov(expr):
+        _, cams = rtx.load_yaml("- add: camera\n  width: 10\n  height: 10\n  field-of-view: %s\n" % expr)
+        hv = cams[0].half_width
+        return 2 * math.atan(hv)
+    assert abs(fov("pi / 2") - math.pi / 2) < 1e-15
+    assert abs(fov("1. / pi") - 1 / math.pi) < 1e-15          # yaml.rs:539-543
+    assert abs(fov("0.25 + 0.25 0.5") - 1.0) < 1e-15
+    assert math.isnan(fov("1 + 2 * 3"))
+    assert abs(fov("1") - 1.0) < 1e-15 and abs(fov("0x1") - 1.0) < 1e-15
+    _, cams = rtx.load_yaml("- add: camera\n  width: 160\n  height: 120\n  field-of-view: pi / 2\n")   # yaml.rs:517-530
+    assert list(cams[0].transform) == list(rtx.API.identity())
+
+
+def test_yaml_errors_instead_of_panics():
+    for bad in ["- define: group\n  transform:\n    - translate: [0, 1, 0]\n",         # Group without name (yaml.rs:331)
+                "- add: sphere\n  material: nope\n",                                    # unknown material
+                "- add: csg\n  operator: union\n",                                      # missing operands (yaml.rs:213)
+                "- add: csg\n  operator: xor\n  operands:\n    - add: sphere\n    - add: cube\n",
+                "- add: camera\n  width: 1.5\n  height: 10\n  field-of-view: 1\n",      # width must be Integer (yaml.rs:77)
+                "just a string\n"]:
+        with pytest.raises(rtx.RtxError):
+            rtx.load_yaml(bad)
+    w, cams = rtx.load_yaml("- add: frobnicator\n- define: thing\n- add: sphere\n  colour: red\n")   # warnings only
+    assert cams == [] and len(rtx.serialize(w)) > 0
+
+
+def test_yaml_flow_and_comments():
+    text = ("# comment\n- add: light   # trailing\n  at: [ -10 , 10, -10 ]\n  intensity: [1, 1, 1]\n"
+            "- define: material\n  name: 'my mat'\n  color: [1, 0.5, 0]\n"
+            "- {add: sphere, material: my mat}\n"
+            "- add: cube\n  transform:\n  - scale: [2, 2, 2]\n  - rotate-y: -pi / 4\n")
+    w1, _ = rtx.load_yaml(text)
+    w2, _ = yaml_scene.load(text, rtx.API)
+    assert rtx.serialize(w1) == rtx.serialize(w2)
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    rtx.write_png(p, img)
+    back = np.asarray(Image.open(p))
+    assert back.shape == img.shape and np.array_equal(back, img)
+
+
+def test_cli_usage_message():
+    out = subprocess.run([os.path.join(ROOT, "ray-tracer_amd", "rtx")], capture_output=True, text=True)
+    assert "Need to provide filename of scene description as argument" in out.stdout     # main.rs:16
+
+
+def test_scene_desc_validation_needs_no_gpu():
+    # rtx_scene_create rejects malformed input before touching the device; here it cannot even get a ctx
+    assert rtx.LIB.rtx_scene_create(None, None, None) == rtx.E_INVALID
+    assert rtx.LIB.rtx_band_rows(100, rtx.Bands(0, 1)) == 104
+    assert rtx.LIB.rtx_band_rows(100, rtx.Bands(1, 2)) == 48 and rtx.LIB.rtx_band_rows(100, rtx.Bands(0, 2)) == 56
+    assert rtx.LIB.rtx_strerror(rtx.E_CAPACITY) is not None
