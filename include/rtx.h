@@ -94,7 +94,16 @@ typedef struct rtx_camera {
 enum {
     RTX_EV_XFORM = 0, RTX_EV_SPHERE, RTX_EV_PLANE, RTX_EV_CUBE, RTX_EV_BOUNDS, RTX_EV_CSG_ENTRIES,
     RTX_EV_HIT, RTX_EV_LEVELS, RTX_EV_LIGHT, RTX_EV_POW, RTX_EV_REFR, RTX_EV_SCHLICK,
-    RTX_EV_COUNT = 16
+    RTX_EV_LANE_SLOTS,   /* diagnostic: 64 x wave-level traces (rays / this = lane packing) */
+    RTX_EV_OP_SLOTS,     /* diagnostic: 64 x traversal ops the waves executed */
+    /* work the kernel actually executes: the conservative bounding-sphere pre-test removes most exact
+       node tests; the reference-defined counts above are unaffected by it */
+    RTX_EV_CULL,         /* pre-tests evaluated (14 f32 flops each) */
+    RTX_EV_X_XFORM,      /* exact ray-into-node transforms executed */
+    RTX_EV_X_SPHERE,     /* exact sphere tests executed */
+    RTX_EV_X_BOX,        /* exact cube / bounds slab tests executed */
+    RTX_EV_USED,
+    RTX_EV_COUNT = 24
 };
 
 typedef struct rtx_stats {

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,7 +48,7 @@ struct rtx_ctx {
 struct rtx_scene {
     rtx_ctx* ctx = nullptr;
     SceneDev dev{};
-    void* d_ops = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
+    void* d_ops = nullptr; void* d_bodies = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
     void* d_materials = nullptr; void* d_lights = nullptr;
 };
 
@@ -72,6 +73,66 @@ bool affine_rows(const double* m, double* rows12, double* w33) {
     return true;
 }
 
+// general 4x4 inverse (Gauss-Jordan, partial pivoting) of a column-major matrix; used only to
+// recover forward transforms for the conservative bounding spheres, never for rendering arithmetic
+bool invert_general(const double* m, double* out) {
+    double a[4][8];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = m[c * 4 + r]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 4; r++) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (!(std::fabs(a[piv][col]) > 0.0) || !std::isfinite(a[piv][col])) return false;
+        if (piv != col) for (int c = 0; c < 8; c++) std::swap(a[piv][c], a[col][c]);
+        const double d = a[col][col];
+        for (int c = 0; c < 8; c++) a[col][c] /= d;
+        for (int r = 0; r < 4; r++) if (r != col) { const double f = a[r][col]; if (f != 0.0) for (int c = 0; c < 8; c++) a[r][c] -= f * a[col][c]; }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[c * 4 + r] = a[r][4 + c];
+    return true;
+}
+
+// Bounding sphere (parent space) of a node whose local extent is the sphere |p - lc| <= lr:
+// centre = T*lc, radius = sigma_max(M) * lr (upper bound), inflated for the f32 pre-test.
+void cull_sphere(const double* inverse16, const double* lc, double lr, float* out4) {
+    out4[0] = out4[1] = out4[2] = 0.f; out4[3] = INFINITY;
+    double fwd[16];
+    if (!std::isfinite(lr) || !invert_general(inverse16, fwd)) return;
+    const double w = fwd[15];
+    if (!(w != 0.0)) return;
+    double c[3], m[3][3];
+    for (int r = 0; r < 3; r++) {
+        c[r] = (fwd[0 * 4 + r] * lc[0] + fwd[1 * 4 + r] * lc[1] + fwd[2 * 4 + r] * lc[2] + fwd[3 * 4 + r]) / w;
+        for (int k = 0; k < 3; k++) m[r][k] = fwd[k * 4 + r] / w;
+    }
+    // upper bound of the largest singular value: Gershgorin on M^T M and on M M^T (same eigenvalues;
+    // one of them is diagonal for scale-then-rotate or rotate-then-scale transforms, so the bound is tight)
+    double ga = 0.0, gb = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double ra = 0.0, rb = 0.0;
+        for (int j = 0; j < 3; j++) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < 3; k++) { a += m[k][i] * m[k][j]; b += m[i][k] * m[j][k]; }
+            ra += std::fabs(a); rb += std::fabs(b);
+        }
+        ga = std::fmax(ga, ra); gb = std::fmax(gb, rb);
+    }
+    const double fro = std::fmin(ga, gb);     // sigma_max^2 <= fro
+    const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    // 0.1 % on the radius, plus the f32 rounding of centre and ray origin (6e-8 relative to their size)
+    const double R = std::sqrt(fro) * lr * 1.001 + 1e-6 * cn + 1e-30;
+    const double r2 = R * R;
+    if (!std::isfinite(r2) || !std::isfinite(cn) || r2 > 1e30) return;
+    for (int k = 0; k < 3; k++) out4[k] = (float)c[k];
+    out4[3] = std::nextafterf((float)r2, INFINITY);
+}
+
+// compile-time view of one op (head + body); split into the two device arrays at upload
+struct OpRec {
+    int32_t kind, level, skip, flags, shape, clevel;
+    float cull[4];
+    double inv[12], w33, bounds[6];
+};
+
 struct Compiler {
     const rtx_scene_desc* d;
     std::vector<OpRec> ops;
@@ -94,6 +155,23 @@ struct Compiler {
                 bad(RTX_E_UNSUPPORTED, "node " + std::to_string(node) + ": transform is not affine");
             if (!(o.w33 == 1.0)) o.flags |= OPF_DIV;
             if (d->node_bounds) std::memcpy(o.bounds, d->node_bounds + (size_t)node * 6, sizeof o.bounds);
+        }
+        o.cull[0] = o.cull[1] = o.cull[2] = 0.f; o.cull[3] = INFINITY;
+        if (node >= 0 && err == RTX_OK) {
+            const double* inv16 = d->node_inverse + (size_t)node * 16;
+            const double zero[3] = {0.0, 0.0, 0.0};
+            if (kind == OPK_SPHERE) cull_sphere(inv16, zero, 1.0, o.cull);
+            else if (kind == OPK_CUBE) cull_sphere(inv16, zero, std::sqrt(3.0), o.cull);
+            else if (kind == OPK_GROUP_BEGIN || kind == OPK_CSG_BEGIN) {
+                const double* b = o.bounds;
+                bool fin = true;
+                for (int k = 0; k < 6; k++) fin = fin && std::isfinite(b[k]);
+                if (fin) {
+                    const double lc[3] = {(b[0] + b[3]) * 0.5, (b[1] + b[4]) * 0.5, (b[2] + b[5]) * 0.5};
+                    const double hx = (b[3] - b[0]) * 0.5, hy = (b[4] - b[1]) * 0.5, hz = (b[5] - b[2]) * 0.5;
+                    cull_sphere(inv16, lc, std::sqrt(hx * hx + hy * hy + hz * hz), o.cull);
+                }
+            }
         }
         return o;
     }
@@ -264,13 +342,30 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     rtx_scene* s = new rtx_scene(); s->ctx = ctx;
     int rc;
-    if ((rc = upload(ctx, cc.ops, &s->d_ops)) || (rc = upload(ctx, cc.shapes, &s->d_shapes)) ||
+    std::vector<OpHead> heads(cc.ops.size() + 2);
+    std::vector<OpBody> bodies(cc.ops.size() + 1);
+    std::memset(heads.data(), 0, heads.size() * sizeof(OpHead));
+    std::memset(bodies.data(), 0, bodies.size() * sizeof(OpBody));
+    for (size_t i = 0; i < cc.ops.size(); i++) {
+        const OpRec& o = cc.ops[i];
+        OpHead& h = heads[i]; OpBody& b = bodies[i];
+        h.info = (uint32_t)o.kind | ((uint32_t)o.flags << 4) | ((uint32_t)o.level << 8) | ((uint32_t)o.clevel << 16);
+        h.skip = o.skip; h.shape = o.shape;
+        std::memcpy(h.cull, o.cull, sizeof h.cull);
+        std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33; std::memcpy(b.bounds, o.bounds, sizeof b.bounds);
+    }
+    for (size_t i = cc.ops.size(); i < heads.size(); i++) { heads[i].info = OPK_GROUP_END; heads[i].cull[3] = INFINITY; }   // padding, never executed
+    if (getenv("RTX_DEBUG"))
+        for (size_t i = 0; i < heads.size(); i++)
+            fprintf(stderr, "head %zu: info=%08x skip=%d shape=%d cull=%g %g %g %g\n", i, heads[i].info, heads[i].skip,
+                    heads[i].shape, heads[i].cull[0], heads[i].cull[1], heads[i].cull[2], heads[i].cull[3]);
+    if ((rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, cc.shapes, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
         (rc = upload(ctx, lights, &s->d_lights))) {
         rtx_scene_destroy(s);
         return rc;
     }
-    s->dev.ops = (const OpRec*)s->d_ops; s->dev.shapes = (const ShapeRec*)s->d_shapes;
+    s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.shapes = (const ShapeRec*)s->d_shapes;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
@@ -284,6 +379,7 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     if (s->d_ops) (void)hipFree(s->d_ops);
+    if (s->d_bodies) (void)hipFree(s->d_bodies);
     if (s->d_shapes) (void)hipFree(s->d_shapes);
     if (s->d_paths) (void)hipFree(s->d_paths);
     if (s->d_materials) (void)hipFree(s->d_materials);

@@ -24,19 +24,27 @@ enum {
     OPF_ROOT = 4       // CSG_BEGIN/CSG_END of a CSG root (a CSG with no CSG ancestor)
 };
 
-// 192 bytes, 64-byte aligned; read through scalar loads (wave-uniform index).
-struct OpRec {
-    int32_t kind;      // OPK_*
-    int32_t level;     // nesting depth: the ray to transform is the local ray of level-1 (0 = world ray)
+// Each op is split into a 32-byte head (all a culled visit touches; the head of the NEXT op is
+// prefetched while the current one is processed) and a 192-byte body (exact test only).  Both are
+// read through scalar loads (wave-uniform index).
+struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
+    uint32_t info;     // kind | flags << 4 | level << 8 | clevel << 16
+                       //   kind: OPK_*; flags: OPF_*; level: nesting depth (the ray to transform is the
+                       //   local ray of level-1, 0 = world ray); clevel: container level inside a CSG root
     int32_t skip;      // BEGIN ops: index just past the matching END
-    int32_t flags;     // OPF_*
     int32_t shape;     // shape ops: ShapeIndex; CSG ops: operator
-    int32_t clevel;    // container nesting level inside the CSG root (list mode)
-    int32_t pad0, pad1;
+    int32_t pad;
+    float cull[4];     // bounding sphere in PARENT space: centre xyz, radius^2 (inflated); +inf = never cull
+};
+#define OPH_KIND(i) ((int)((i) & 15u))
+#define OPH_FLAGS(i) ((int)(((i) >> 4) & 15u))
+#define OPH_LEVEL(i) ((int)(((i) >> 8) & 255u))
+#define OPH_CLEVEL(i) ((int)(((i) >> 16) & 255u))
+struct OpBody {
     double inv[12];    // rows 0..2 of inverse(transform): inv[r*4+c]
     double w33;        // inverse(3,3)
     double bounds[6];  // containers: local bounds {min xyz, max xyz}
-    double pad2;
+    double pad[5];
 };
 
 // per ShapeIndex
@@ -59,7 +67,8 @@ struct MaterialRec {     // 208 bytes
 struct LightRec { double pos[3]; double intensity[3]; };
 
 struct SceneDev {
-    const OpRec* ops;
+    const OpHead* heads;      // n_ops + 2 entries (padding so the 2-deep prefetch never runs off the end)
+    const OpBody* bodies;
     const ShapeRec* shapes;
     const int32_t* path_ops;
     const MaterialRec* materials;
@@ -90,6 +99,6 @@ struct RenderParams {
 #define RTX_CNT_SHADOW 1
 #define RTX_CNT_OVERFLOW 2
 #define RTX_CNT_EV0 3
-#define RTX_CNT_TOTAL (3 + 16)
+#define RTX_CNT_TOTAL (3 + 24)
 
 #endif

@@ -45,6 +45,8 @@ DI V3 normalize3(V3 a) { return a / norm3(a); }            // unscale: component
 DI V3 reflect3(V3 v, V3 n) { return v - n * 2.0 * dot3(v, n); }   // geometry.rs:49-51
 
 #define INF __builtin_inf()
+#define LDS_LEVEL_DOUBLES 576          // per level: 6 x 64 doubles + 6 x 64 floats (f32 copy for the pre-test)
+#define CULL_KAPPA 1.0e-5f             // relative slack on |oc|^2 covering f32 rounding of the pre-test
 
 // Projective3 * Point3 with an affine matrix: (M3x3 p + t) / w33   (rows m[r*4+c])
 template <typename P>
@@ -141,6 +143,30 @@ struct Frame {           // one pending shade_hit (world.rs:127-149) waiting for
     int32_t remaining;   // the `remaining` this shade_hit was called with
 };
 
+// One op head = 8 dwords fetched with a single scalar s_load_dwordx8 (constant address space) and
+// kept as a uniform vector: [0] info, [1] skip, [2] shape, [4..7] cull sphere (cx, cy, cz, r^2).
+typedef uint32_t Head __attribute__((ext_vector_type(8)));
+DI Head load_head(const AS4 OpHead* p) { return *(const AS4 Head*)p; }
+#define H_INFO(h) ((h)[0])
+#define H_SKIP(h) ((int)(h)[1])
+#define H_SHAPE(h) ((int)(h)[2])
+// (bit_cast straight on a vector element reads element 0: go through a scalar temporary)
+DI float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+#define H_CULL(h, i) as_f32((h)[4 + (i)])
+
+// conservative bounding-sphere pre-test (no counterpart in the reference; it cannot change a result):
+// the node lies inside the sphere (centre c, radius^2 r2) of its parent's space.  A line whose
+// distance to c exceeds the radius by the margins folded into r2 and CULL_KAPPA has no intersection
+// with the node at ANY t, so the reference's exact test would return an empty list as well.
+DI bool cull_miss(Head h, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd) {
+    const float ocx = H_CULL(h, 0) - fox, ocy = H_CULL(h, 1) - foy, ocz = H_CULL(h, 2) - foz;
+    const float od = __builtin_fmaf(ocz, fdz, __builtin_fmaf(ocy, fdy, ocx * fdx));
+    const float oo = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+    const float lhs = __builtin_fmaf(oo, fdd, -(od * od));            // dist^2 * |d|^2
+    const float rhs = __builtin_fmaf(CULL_KAPPA, oo, H_CULL(h, 3)) * fdd;
+    return lhs > rhs;                                                 // false on NaN
+}
+
 enum { MODE_DONE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
 const uint32_t LBIT = 0x80000000u;
 
@@ -160,16 +186,17 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
     const int py = band * RTX_TILE + (lane >> 3);
     const bool valid = px < cam.hsize && py < cam.vsize;
 
-    const AS4 OpRec* ops = (const AS4 OpRec*)(uintptr_t)sc.ops;
+    const AS4 OpHead* heads = (const AS4 OpHead*)(uintptr_t)sc.heads;
+    const AS4 OpBody* bodies = (const AS4 OpBody*)(uintptr_t)sc.bodies;
     const int n_ops = sc.n_ops;
     const int n_lights = sc.n_lights;
 
     // ---- per-lane counters
     unsigned n_radiance = 0, n_shadow = 0, overflow = 0;
-    unsigned ev[12];
+    unsigned ev[RTX_EV_USED];             // reference-defined events + executed-work and occupancy diagnostics
     if (COUNT) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) ev[i] = 0;
+        for (int i = 0; i < RTX_EV_USED; i++) ev[i] = 0;
     }
 #define EV(e, n) do { if (COUNT) ev[e] += (n); } while (0)
 
@@ -211,6 +238,7 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
         // World::intersect (world.rs:111-118) for every lane's current ray.
         if (mode == MODE_RADIANCE) n_radiance++;
         else if (mode == MODE_SHADOW) n_shadow++;
+        EV(RTX_EV_LANE_SLOTS, 1);         // every lane, busy or not: 64 per wave trace
 
         bool have = false; double best_t = 0.0; int best_shape = -1; bool best_inside = false;
         double c1t = -INF, c2t = -INF; int c1s = -1, c2s = -1;     // refractive containers (§9.3)
@@ -237,36 +265,97 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
             }
         };
 
+        // parent-space ray of the level being walked: f64 for the exact tests, an f32 copy for the
+        // conservative bounding-sphere pre-test.  Level 0 = the world ray; deeper levels are
+        // re-read from the LDS stack when the walk returns to them.
+        V3 po = ro, pd = rd;
+        float fox = (float)ro.x, foy = (float)ro.y, foz = (float)ro.z;
+        float fdx = (float)rd.x, fdy = (float)rd.y, fdz = (float)rd.z;
+        float fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+        int cached_level = 0;
+
         int cur = 0;
+        Head h = load_head(heads), hn = load_head(heads + 1);   // heads[] carries 2 padding records
         while (cur < n_ops) {
-            cur = __builtin_amdgcn_readfirstlane(cur);
-            const bool active = cur >= resume_at;
-            if (!__any(active)) {
-                cur = wave_min(resume_at);
-                continue;
+            // ---- fast-forward: ops no lane needs touch no per-lane state (tight scalar loop)
+            for (bool ffwd = true; ffwd;) {
+                cur = __builtin_amdgcn_readfirstlane(cur);
+                cached_level = __builtin_amdgcn_readfirstlane(cached_level);
+                const bool act = cur >= resume_at;
+                const int k0 = OPH_KIND(H_INFO(h));
+                int nxt = -1;                                    // -1: this op needs the general body
+                if (!__any(act)) nxt = __builtin_amdgcn_readfirstlane(wave_min(resume_at));
+                else if (COUNT) nxt = -1;                        // counting build: every op goes the long way
+                else if (k0 == OPK_GROUP_END && !(OPH_FLAGS(H_INFO(h)) & OPF_LIST)) nxt = cur + 1;
+                else if (k0 <= OPK_CSG_BEGIN && k0 != OPK_GROUP_END && H_CULL(h, 3) < __builtin_inff() &&
+                         OPH_LEVEL(H_INFO(h)) == cached_level) {
+                    const bool miss = cull_miss(h, fox, foy, foz, fdx, fdy, fdz, fdd);
+                    if (!__any(act && !miss)) nxt = (k0 > OPK_CUBE) ? H_SKIP(h) : cur + 1;
+                }
+                if (nxt < 0) ffwd = false;
+                else {
+                    if (nxt == cur + 1) { h = hn; hn = load_head(heads + cur + 2); }
+                    else { h = load_head(heads + nxt); hn = load_head(heads + nxt + 1); }
+                    cur = nxt;
+                    if (cur >= n_ops) ffwd = false;
+                }
             }
-            const AS4 OpRec* op = ops + cur;
-            const int kind = op->kind;
-            const int level = op->level;
-            const int flags = op->flags;
+            if (cur >= n_ops) break;
+            const bool active = cur >= resume_at;
+            const AS4 OpBody* op = bodies + cur;
+            EV(RTX_EV_OP_SLOTS, 1);       // every lane: 64 per op the wave executes
+            const int kind = OPH_KIND(H_INFO(h));
+            const int level = OPH_LEVEL(H_INFO(h));
+            const int flags = OPH_FLAGS(H_INFO(h));
             int next = cur + 1;
 
             if (kind <= OPK_CSG_BEGIN && kind != OPK_GROUP_END) {
-                // ---- ObjectStore::intersect (object_store.rs:243-260): ray into node space
-                V3 po, pd;
-                if (level == 0) { po = ro; pd = rd; }
-                else {
-                    const double* s = lds_rays + (level - 1) * 384 + lane;
-                    po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
+                const bool container = kind > OPK_CUBE;
+                if (level != cached_level) {
+                    if (level == 0) {
+                        po = ro; pd = rd;
+                        fox = (float)ro.x; foy = (float)ro.y; foz = (float)ro.z;
+                        fdx = (float)rd.x; fdy = (float)rd.y; fdz = (float)rd.z;
+                    } else {
+                        const double* s = lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + lane;
+                        po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
+                        const float* f = (const float*)(lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + 384) + lane;
+                        fox = f[0]; foy = f[64]; foz = f[128]; fdx = f[192]; fdy = f[256]; fdz = f[320];
+                    }
+                    fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+                    cached_level = level;
                 }
+                if (active) {
+                    EV(RTX_EV_XFORM, 1);
+                    if (kind == OPK_SPHERE) EV(RTX_EV_SPHERE, 1);
+                    else if (kind == OPK_PLANE) EV(RTX_EV_PLANE, 1);
+                    else if (kind == OPK_CUBE) EV(RTX_EV_CUBE, 1);
+                    else EV(RTX_EV_BOUNDS, 1);
+                }
+                // ---- conservative pre-test (no counterpart in the reference; cannot change a result):
+                // the node lies inside a bounding sphere (centre c, radius^2 r2, parent space).  A line
+                // whose distance to c exceeds the radius by the margins below has no intersection with
+                // the node at ANY t, so the reference's exact test would return an empty list too.
+                bool test = active;
+                const float r2 = H_CULL(h, 3);
+                if (r2 < __builtin_inff()) {
+                    const bool miss = cull_miss(h, fox, foy, foz, fdx, fdy, fdz, fdd);
+                    if (active) EV(RTX_EV_CULL, 1);
+                    test = active && !miss;
+                    if (container && active && miss) resume_at = H_SKIP(h);
+                }
+                if (!__any(test)) {
+                    if (container) next = H_SKIP(h);
+                } else {
+                // ---- ObjectStore::intersect (object_store.rs:243-260): ray into node space
                 V3 lo = xf_point(op->inv, op->w33, (flags & OPF_DIV) != 0, po);
                 V3 ld = xf_vector(op->inv, pd);
-                if (active) EV(RTX_EV_XFORM, 1);
+                if (test) EV(RTX_EV_X_XFORM, 1);
 
-                if (kind <= OPK_CUBE) {
+                if (!container) {
                     int k = 0; double t0 = 0.0, t1 = 0.0;
                     if (kind == OPK_SPHERE) {                 // sphere.rs:16-32
-                        if (active) EV(RTX_EV_SPHERE, 1);
+                        if (test) EV(RTX_EV_X_SPHERE, 1);
                         double a = dot3(ld, ld);
                         double b = 2.0 * dot3(ld, lo);
                         double c = dot3(lo, lo) - 1.0;
@@ -278,14 +367,13 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                             k = 2;
                         }
                     } else if (kind == OPK_PLANE) {           // plane.rs:16-23
-                        if (active) EV(RTX_EV_PLANE, 1);
                         if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
                     } else {                                  // cube.rs:18-31
-                        if (active) EV(RTX_EV_CUBE, 1);
+                        if (test) EV(RTX_EV_X_BOX, 1);
                         if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
                     }
-                    if (active) {
-                        const int shape = op->shape;
+                    if (test) {
+                        const int shape = H_SHAPE(h);
                         if (CSG && (flags & OPF_LIST)) {
                             if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
                             if (k >= 1) { lt[cnt] = t0; ls[cnt] = (uint32_t)shape; cnt++; }
@@ -298,28 +386,37 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                     }
                 } else {
                     // ---- Groups::local_intersect (group.rs:64-75) / CSGs::local_intersect (csg.rs:73-78)
-                    if (active) EV(RTX_EV_BOUNDS, 1);
+                    if (test) EV(RTX_EV_X_BOX, 1);
                     double tmin, tmax;
                     bool pass = slabs(lo, ld, op->bounds[0], op->bounds[1], op->bounds[2],
                                       op->bounds[3], op->bounds[4], op->bounds[5], tmin, tmax);
-                    pass = pass && active;
-                    if (active && !pass) resume_at = op->skip;
+                    pass = pass && test;
+                    if (test && !pass) resume_at = H_SKIP(h);
                     if (!__any(pass)) {
-                        next = op->skip;
+                        next = H_SKIP(h);
                     } else {
-                        double* s = lds_rays + level * 384 + lane;
+                        double* s = lds_rays + level * LDS_LEVEL_DOUBLES + lane;
+                        float* f = (float*)(lds_rays + level * LDS_LEVEL_DOUBLES + 384) + lane;
+                        // the children (level + 1) walk in this node's space
+                        po = lo; pd = ld;
+                        fox = (float)lo.x; foy = (float)lo.y; foz = (float)lo.z;
+                        fdx = (float)ld.x; fdy = (float)ld.y; fdz = (float)ld.z;
+                        fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+                        cached_level = level + 1;
                         if (pass) {
                             s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
                             s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
+                            f[0] = fox; f[64] = foy; f[128] = foz; f[192] = fdx; f[256] = fdy; f[320] = fdz;
                             if (CSG && (flags & OPF_LIST)) {
-                                const int sh = op->clevel * 8;
+                                const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
                                 starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                             }
                         }
                     }
                 }
+                }
             } else if (CSG && (flags & OPF_LIST) && active) {
-                const int sh = op->clevel * 8;
+                const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
                 if (kind == OPK_CSG_MID) {
                     mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                 } else {
@@ -338,7 +435,7 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                     }
                     if (kind == OPK_CSG_END) {
                         // filter_intersections (csg.rs:94-121)
-                        const int cop = op->shape;
+                        const int cop = H_SHAPE(h);
                         bool inl = false, inr = false;
                         int out = s0;
                         for (int i = s0; i < cnt; i++) {
@@ -389,6 +486,8 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                     }
                 }
             }
+            if (next == cur + 1) { h = hn; hn = load_head(heads + cur + 2); }
+            else { h = load_head(heads + next); hn = load_head(heads + next + 1); }
             cur = next;
         }
 
@@ -412,8 +511,9 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                 // world_to_object (object_store.rs:309-320): root -> shape
                 V3 objp = hp;
                 for (int i = 0; i < srec.path_len; i++) {
-                    const OpRec* xo = sc.ops + sc.path_ops[srec.path_begin + i];
-                    objp = xf_point(xo->inv, xo->w33, (xo->flags & OPF_DIV) != 0, objp);
+                    const int pi = sc.path_ops[srec.path_begin + i];
+                    const OpBody* xo = sc.bodies + pi;
+                    objp = xf_point(xo->inv, xo->w33, (OPH_FLAGS(sc.heads[pi].info) & OPF_DIV) != 0, objp);
                 }
                 V3 ln;
                 if (srec.type == OPK_SPHERE) ln = objp;                          // sphere.rs:34-36
@@ -427,7 +527,7 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                 }
                 // normal_to_world (object_store.rs:331-349): shape -> root, normalised per level
                 for (int i = srec.path_len - 1; i >= 0; i--) {
-                    const OpRec* xo = sc.ops + sc.path_ops[srec.path_begin + i];
+                    const OpBody* xo = sc.bodies + sc.path_ops[srec.path_begin + i];
                     ln = normalize3(xf_normal(xo->inv, ln));
                 }
                 nv = ln;
@@ -637,7 +737,7 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
     }
     if (COUNT) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
+        for (int i = 0; i < RTX_EV_USED; i++) {
             unsigned s = wave_sum(ev[i]);
             if (lane == 0 && s) atomicAdd(&counters[RTX_CNT_EV0 + i], (unsigned long long)s);
         }
@@ -651,7 +751,7 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
                                              int count_events, hipStream_t stream) {
     const int blocks = rp->tiles_x * rp->n_bands_local;
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = (size_t)sc->n_levels * 6 * 64 * sizeof(double);
+    const size_t lds = (size_t)sc->n_levels * LDS_LEVEL_DOUBLES * sizeof(double);
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
     if (count_events) {

@@ -20,9 +20,12 @@ PAT_PLAIN, PAT_STRIPES, PAT_RINGS, PAT_CHECKERS, PAT_GRADIENT, PAT_TEST = range(
 D3 = C.c_double * 3
 D6 = C.c_double * 6
 D16 = C.c_double * 16
-EV_COUNT = 16
+EV_COUNT = 16          # oracle stats layout (oracle/rt_oracle.h)
 EV_NAMES = ["xform", "sphere", "plane", "cube", "bounds", "csg_entries", "hit", "levels",
-            "light", "pow", "refr", "schlick"]
+            "light", "pow", "refr", "schlick", "lane_slots", "op_slots", "cull", "x_xform", "x_sphere", "x_box"]
+
+
+REF_EVENTS = EV_NAMES[:12]          # reference-defined events (the oracle counts exactly these)
 
 
 class Material(C.Structure):
@@ -53,7 +56,7 @@ class Stats(C.Structure):
         return self.rays_primary + self.rays_shadow + self.rays_secondary
 
     def events(self):
-        return {n: int(self.ev[i]) for i, n in enumerate(EV_NAMES)}
+        return {n: int(self.ev[i]) for i, n in enumerate(EV_NAMES) if i < len(self.ev)}
 
 
 def d3(v):

@@ -29,7 +29,7 @@ class RtxError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_secondary", C.c_uint64),
-                ("ev", C.c_uint64 * rtapi.EV_COUNT), ("overflow_pixels", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("ev", C.c_uint64 * 24), ("overflow_pixels", C.c_uint64), ("kernel_ms", C.c_double)]
 
     @property
     def rays(self):
