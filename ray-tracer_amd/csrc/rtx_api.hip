@@ -215,7 +215,7 @@ struct Compiler {
             stack.push_back(b);
             for (int i = 0; i < nc; i++) entries += emit(d->children[fc + i], level + 1, list, clevel + 1);
             stack.pop_back();
-            ops.push_back(make(-1, OPK_GROUP_END, level, lf, clevel));
+            if (list) ops.push_back(make(-1, OPK_GROUP_END, level, lf, clevel));   // outside CSG an END has nothing to do
             ops[b].skip = (int)ops.size();
         } else {
             if (nc != 2) { bad(RTX_E_INVALID, "CSG node needs exactly 2 children"); return 0; }
@@ -353,6 +353,18 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         h.skip = o.skip; h.shape = o.shape;
         std::memcpy(h.cull, o.cull, sizeof h.cull);
         std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33; std::memcpy(b.bounds, o.bounds, sizeof b.bounds);
+    }
+    // runs of consecutive shapes with the same level and list flag, at most 64 long (one candidate bit each)
+    for (size_t i = cc.ops.size(); i-- > 0;) {
+        const OpRec& o = cc.ops[i];
+        if (o.kind > OPK_CUBE) continue;
+        int run = 1;
+        if (i + 1 < cc.ops.size()) {
+            const OpRec& nx = cc.ops[i + 1];
+            if (nx.kind <= OPK_CUBE && nx.level == o.level && ((nx.flags ^ o.flags) & OPF_LIST) == 0 && heads[i + 1].run < 64)
+                run = heads[i + 1].run + 1;
+        }
+        heads[i].run = run;
     }
     for (size_t i = cc.ops.size(); i < heads.size(); i++) { heads[i].info = OPK_GROUP_END; heads[i].cull[3] = INFINITY; }   // padding, never executed
     if (getenv("RTX_DEBUG"))

@@ -33,7 +33,7 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
                        //   local ray of level-1, 0 = world ray); clevel: container level inside a CSG root
     int32_t skip;      // BEGIN ops: index just past the matching END
     int32_t shape;     // shape ops: ShapeIndex; CSG ops: operator
-    int32_t pad;
+    int32_t run;       // shape ops: ops left in this run of consecutive same-level shapes (1..64), else 0
     float cull[4];     // bounding sphere in PARENT space: centre xyz, radius^2 (inflated); +inf = never cull
 };
 #define OPH_KIND(i) ((int)((i) & 15u))

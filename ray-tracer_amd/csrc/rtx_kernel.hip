@@ -150,6 +150,7 @@ DI Head load_head(const AS4 OpHead* p) { return *(const AS4 Head*)p; }
 #define H_INFO(h) ((h)[0])
 #define H_SKIP(h) ((int)(h)[1])
 #define H_SHAPE(h) ((int)(h)[2])
+#define H_RUN(h) ((int)(h)[3])
 // (bit_cast straight on a vector element reads element 0: go through a scalar temporary)
 DI float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 #define H_CULL(h, i) as_f32((h)[4 + (i)])
@@ -172,8 +173,15 @@ const uint32_t LBIT = 0x80000000u;
 
 }  // namespace
 
+// occupancy target (waves per SIMD): the kernel is instruction-issue bound, a wave issues at most one
+// instruction every 4 cycles, so more resident waves fill the issue slots; the register allocator
+// spills the long-lived shading context (live across, not inside, the traversal loop) to scratch.
+#ifndef RTX_MIN_WAVES
+#define RTX_MIN_WAVES 4
+#endif
+
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
+__global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
                                                          unsigned long long* __restrict__ counters) {
@@ -199,6 +207,12 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
         for (int i = 0; i < RTX_EV_USED; i++) ev[i] = 0;
     }
 #define EV(e, n) do { if (COUNT) ev[e] += (n); } while (0)
+#ifdef RTX_TIMING
+    unsigned long long tm_ffwd = 0, tm_body = 0, tm_shade = 0, tm_other = 0, tm_mark = __builtin_amdgcn_s_memtime();
+#define TM(acc) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_mark; tm_mark = now_; } while (0)
+#else
+#define TM(acc) do { } while (0)
+#endif
 
     // ---- Camera::ray_for_pixel (camera.rs:56-69)
     V3 ro, rd;
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
     uint32_t ls[CSG ? RTX_MAX_CSG_ENTRIES : 1];
 
     while (__any(mode != MODE_DONE)) {
+        TM(tm_shade);
         // ================================================================= TRACE
         // World::intersect (world.rs:111-118) for every lane's current ray.
         if (mode == MODE_RADIANCE) n_radiance++;
@@ -274,106 +289,101 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
         float fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
         int cached_level = 0;
 
-        int cur = 0;
-        Head h = load_head(heads), hn = load_head(heads + 1);   // heads[] carries 2 padding records
-        while (cur < n_ops) {
-            // ---- fast-forward: ops no lane needs touch no per-lane state (tight scalar loop)
-            for (bool ffwd = true; ffwd;) {
-                cur = __builtin_amdgcn_readfirstlane(cur);
-                cached_level = __builtin_amdgcn_readfirstlane(cached_level);
-                const bool act = cur >= resume_at;
-                const int k0 = OPH_KIND(H_INFO(h));
-                int nxt = -1;                                    // -1: this op needs the general body
-                if (!__any(act)) nxt = __builtin_amdgcn_readfirstlane(wave_min(resume_at));
-                else if (COUNT) nxt = -1;                        // counting build: every op goes the long way
-                else if (k0 == OPK_GROUP_END && !(OPH_FLAGS(H_INFO(h)) & OPF_LIST)) nxt = cur + 1;
-                else if (k0 <= OPK_CSG_BEGIN && k0 != OPK_GROUP_END && H_CULL(h, 3) < __builtin_inff() &&
-                         OPH_LEVEL(H_INFO(h)) == cached_level) {
-                    const bool miss = cull_miss(h, fox, foy, foz, fdx, fdy, fdz, fdd);
-                    if (!__any(act && !miss)) nxt = (k0 > OPK_CUBE) ? H_SKIP(h) : cur + 1;
-                }
-                if (nxt < 0) ffwd = false;
-                else {
-                    if (nxt == cur + 1) { h = hn; hn = load_head(heads + cur + 2); }
-                    else { h = load_head(heads + nxt); hn = load_head(heads + nxt + 1); }
-                    cur = nxt;
-                    if (cur >= n_ops) ffwd = false;
-                }
+        // reload the parent-space ray when the walk changes level (uniform)
+        auto sync_level = [&](int level) {
+            if (level == cached_level) return;
+            if (level == 0) {
+                po = ro; pd = rd;
+                fox = (float)ro.x; foy = (float)ro.y; foz = (float)ro.z;
+                fdx = (float)rd.x; fdy = (float)rd.y; fdz = (float)rd.z;
+            } else {
+                const double* s = lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + lane;
+                po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
+                const float* f = (const float*)(lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + 384) + lane;
+                fox = f[0]; foy = f[64]; foz = f[128]; fdx = f[192]; fdy = f[256]; fdz = f[320];
             }
-            if (cur >= n_ops) break;
+            fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+            cached_level = level;
+        };
+
+        int cur = 0;
+        while (cur < n_ops) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            cached_level = __builtin_amdgcn_readfirstlane(cached_level);
             const bool active = cur >= resume_at;
-            const AS4 OpBody* op = bodies + cur;
-            EV(RTX_EV_OP_SLOTS, 1);       // every lane: 64 per op the wave executes
+            if (!__any(active)) {
+                cur = __builtin_amdgcn_readfirstlane(wave_min(resume_at));   // keep the op index scalar
+                continue;
+            }
+            const Head h = load_head(heads + cur);
             const int kind = OPH_KIND(H_INFO(h));
             const int level = OPH_LEVEL(H_INFO(h));
             const int flags = OPH_FLAGS(H_INFO(h));
             int next = cur + 1;
 
-            if (kind <= OPK_CSG_BEGIN && kind != OPK_GROUP_END) {
-                const bool container = kind > OPK_CUBE;
-                if (level != cached_level) {
-                    if (level == 0) {
-                        po = ro; pd = rd;
-                        fox = (float)ro.x; foy = (float)ro.y; foz = (float)ro.z;
-                        fdx = (float)rd.x; fdy = (float)rd.y; fdz = (float)rd.z;
-                    } else {
-                        const double* s = lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + lane;
-                        po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
-                        const float* f = (const float*)(lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + 384) + lane;
-                        fox = f[0]; foy = f[64]; foz = f[128]; fdx = f[192]; fdy = f[256]; fdz = f[320];
-                    }
-                    fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
-                    cached_level = level;
-                }
-                if (active) {
-                    EV(RTX_EV_XFORM, 1);
-                    if (kind == OPK_SPHERE) EV(RTX_EV_SPHERE, 1);
-                    else if (kind == OPK_PLANE) EV(RTX_EV_PLANE, 1);
-                    else if (kind == OPK_CUBE) EV(RTX_EV_CUBE, 1);
-                    else EV(RTX_EV_BOUNDS, 1);
-                }
-                // ---- conservative pre-test (no counterpart in the reference; cannot change a result):
-                // the node lies inside a bounding sphere (centre c, radius^2 r2, parent space).  A line
-                // whose distance to c exceeds the radius by the margins below has no intersection with
-                // the node at ANY t, so the reference's exact test would return an empty list too.
-                bool test = active;
-                const float r2 = H_CULL(h, 3);
-                if (r2 < __builtin_inff()) {
-                    const bool miss = cull_miss(h, fox, foy, foz, fdx, fdy, fdz, fdd);
-                    if (active) EV(RTX_EV_CULL, 1);
-                    test = active && !miss;
-                    if (container && active && miss) resume_at = H_SKIP(h);
-                }
-                if (!__any(test)) {
-                    if (container) next = H_SKIP(h);
-                } else {
-                // ---- ObjectStore::intersect (object_store.rs:243-260): ray into node space
-                V3 lo = xf_point(op->inv, op->w33, (flags & OPF_DIV) != 0, po);
-                V3 ld = xf_vector(op->inv, pd);
-                if (test) EV(RTX_EV_X_XFORM, 1);
-
-                if (!container) {
-                    int k = 0; double t0 = 0.0, t1 = 0.0;
-                    if (kind == OPK_SPHERE) {                 // sphere.rs:16-32
-                        if (test) EV(RTX_EV_X_SPHERE, 1);
-                        double a = dot3(ld, ld);
-                        double b = 2.0 * dot3(ld, lo);
-                        double c = dot3(lo, lo) - 1.0;
-                        double disc = b * b - 4.0 * a * c;
-                        if (!(disc < 0.0)) {
-                            double sq = __builtin_sqrt(disc);
-                            t0 = (-b - sq) / (2.0 * a);
-                            t1 = (-b + sq) / (2.0 * a);
-                            k = 2;
+            if (kind <= OPK_CUBE) {
+                // ================= a RUN of consecutive shapes of one level (host-marked, <= 64 ops)
+                TM(tm_other);
+                const int R = H_RUN(h);
+                sync_level(level);
+                // ---- phase 1: conservative bounding-sphere pre-test of every op of the run for every
+                // lane (cull_miss: no counterpart in the reference, cannot change a result).  Tight
+                // uniform loop: one scalar head load + ~16 f32 VALU per op, no per-lane state but `cand`.
+                uint64_t cand = 0;
+                {
+                    Head hh = h;
+                    for (int i = 0; i < R; i++) {
+                        const Head hnext = load_head(heads + cur + i + 1);     // prefetch (array is padded)
+                        const bool miss = cull_miss(hh, fox, foy, foz, fdx, fdy, fdz, fdd);
+                        cand |= miss ? 0ull : (1ull << i);
+                        if (COUNT && active) {
+                            const int kk = OPH_KIND(H_INFO(hh));
+                            EV(RTX_EV_XFORM, 1); EV(RTX_EV_CULL, 1);
+                            if (kk == OPK_SPHERE) EV(RTX_EV_SPHERE, 1);
+                            else if (kk == OPK_PLANE) EV(RTX_EV_PLANE, 1);
+                            else EV(RTX_EV_CUBE, 1);
                         }
-                    } else if (kind == OPK_PLANE) {           // plane.rs:16-23
-                        if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
-                    } else {                                  // cube.rs:18-31
-                        if (test) EV(RTX_EV_X_BOX, 1);
-                        if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
+                        hh = hnext;
                     }
-                    if (test) {
-                        const int shape = H_SHAPE(h);
+                }
+                if (!active) cand = 0;
+                EV(RTX_EV_OP_SLOTS, R);
+                TM(tm_ffwd);
+                // ---- phase 2: every lane walks ITS OWN surviving ops in program order (lowest bit first,
+                // so ties resolve as in the reference's stable sort); node records come through per-lane
+                // vector loads.  ObjectStore::intersect (object_store.rs:243-260) for one shape per lane.
+                while (__any(cand != 0)) {
+                    if (cand != 0) {
+                        const int i = __builtin_ctzll(cand);
+                        cand &= cand - 1;
+                        const int idx = cur + i;
+                        const OpHead* gh = sc.heads + idx;
+                        const OpBody* gb = sc.bodies + idx;
+                        const uint32_t info = gh->info;
+                        const int k1 = OPH_KIND(info);
+                        const int shape = gh->shape;
+                        V3 lo = xf_point(gb->inv, gb->w33, (OPH_FLAGS(info) & OPF_DIV) != 0, po);
+                        V3 ld = xf_vector(gb->inv, pd);
+                        EV(RTX_EV_X_XFORM, 1);
+                        int k = 0; double t0 = 0.0, t1 = 0.0;
+                        if (k1 == OPK_SPHERE) {                   // sphere.rs:16-32
+                            EV(RTX_EV_X_SPHERE, 1);
+                            double a = dot3(ld, ld);
+                            double b = 2.0 * dot3(ld, lo);
+                            double c = dot3(lo, lo) - 1.0;
+                            double disc = b * b - 4.0 * a * c;
+                            if (!(disc < 0.0)) {
+                                double sq = __builtin_sqrt(disc);
+                                t0 = (-b - sq) / (2.0 * a);
+                                t1 = (-b + sq) / (2.0 * a);
+                                k = 2;
+                            }
+                        } else if (k1 == OPK_PLANE) {             // plane.rs:16-23
+                            if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
+                        } else {                                  // cube.rs:18-31
+                            EV(RTX_EV_X_BOX, 1);
+                            if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
+                        }
                         if (CSG && (flags & OPF_LIST)) {
                             if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
                             if (k >= 1) { lt[cnt] = t0; ls[cnt] = (uint32_t)shape; cnt++; }
@@ -381,12 +391,32 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                         } else {
                             feed(k, t0, t1, shape);
                             // is_shadowed (world.rs:203-206): any 0 <= t < distance decides
-                            if (is_shadow && !rp.no_early_out && have && best_t < shadow_dist) resume_at = n_ops;
+                            if (is_shadow && !rp.no_early_out && have && best_t < shadow_dist) { resume_at = n_ops; cand = 0; }
                         }
                     }
+                }
+                next = cur + R;
+                TM(tm_body);
+            } else if (kind == OPK_GROUP_BEGIN || kind == OPK_CSG_BEGIN) {
+                sync_level(level);
+                if (active) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_BOUNDS, 1); }
+                EV(RTX_EV_OP_SLOTS, 1);
+                // conservative pre-test of the container's bounding sphere (see cull_miss)
+                bool test = active;
+                if (H_CULL(h, 3) < __builtin_inff()) {
+                    const bool miss = cull_miss(h, fox, foy, foz, fdx, fdy, fdz, fdd);
+                    if (active) EV(RTX_EV_CULL, 1);
+                    test = active && !miss;
+                    if (active && miss) resume_at = H_SKIP(h);
+                }
+                if (!__any(test)) {
+                    next = H_SKIP(h);
                 } else {
                     // ---- Groups::local_intersect (group.rs:64-75) / CSGs::local_intersect (csg.rs:73-78)
-                    if (test) EV(RTX_EV_X_BOX, 1);
+                    const AS4 OpBody* op = bodies + cur;
+                    V3 lo = xf_point(op->inv, op->w33, (flags & OPF_DIV) != 0, po);
+                    V3 ld = xf_vector(op->inv, pd);
+                    if (test) { EV(RTX_EV_X_XFORM, 1); EV(RTX_EV_X_BOX, 1); }
                     double tmin, tmax;
                     bool pass = slabs(lo, ld, op->bounds[0], op->bounds[1], op->bounds[2],
                                       op->bounds[3], op->bounds[4], op->bounds[5], tmin, tmax);
@@ -413,7 +443,6 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                             }
                         }
                     }
-                }
                 }
             } else if (CSG && (flags & OPF_LIST) && active) {
                 const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
@@ -486,11 +515,10 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
                     }
                 }
             }
-            if (next == cur + 1) { h = hn; hn = load_head(heads + cur + 2); }
-            else { h = load_head(heads + next); hn = load_head(heads + next + 1); }
             cur = next;
         }
 
+        TM(tm_other);
         // ================================================================= SHADE
         bool returning = false;                 // lane has a finished colour to hand to its parent frame
         double rr = 0.0, rg = 0.0, rb = 0.0;
@@ -728,6 +756,14 @@ __global__ __launch_bounds__(64) void trace_shade_kernel(SceneDev sc, CameraDev 
         if (hit_out) hit_out[idx] = primary_id;
     }
 
+#ifdef RTX_TIMING
+    if (lane == 0) {
+        atomicAdd(&counters[RTX_CNT_EV0 + 18], tm_ffwd);
+        atomicAdd(&counters[RTX_CNT_EV0 + 19], tm_body);
+        atomicAdd(&counters[RTX_CNT_EV0 + 20], tm_shade);
+        atomicAdd(&counters[RTX_CNT_EV0 + 21], tm_other);
+    }
+#endif
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow);
     if (lane == 0) {

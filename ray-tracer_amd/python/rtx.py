@@ -13,7 +13,7 @@ from rtapi import Camera, Material, d3  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(_HERE)
 ROOT = os.path.dirname(PKG)
-LIB_PATH = os.path.join(PKG, "librtx_hip.so")
+LIB_PATH = os.path.join(PKG, os.environ.get("RTX_LIB", "librtx_hip.so"))
 
 OK, E_INVALID, E_DEVICE, E_CAPACITY, E_UNSUPPORTED = 0, -1, -2, -3, -4
 F_COUNT_EVENTS, F_NO_SHADOW_EARLY_OUT, F_BANDS_COMPACT = 1, 2, 4
