@@ -20,7 +20,7 @@ PAT_PLAIN, PAT_STRIPES, PAT_RINGS, PAT_CHECKERS, PAT_GRADIENT, PAT_TEST = range(
 D3 = C.c_double * 3
 D6 = C.c_double * 6
 D16 = C.c_double * 16
-EV_COUNT = 16          # oracle stats layout (oracle/rt_oracle.h)
+EV_COUNT = 16          # event slots of the host-API stats struct (the device stats in rtx.py hold 24)
 EV_NAMES = ["xform", "sphere", "plane", "cube", "bounds", "csg_entries", "hit", "levels",
             "light", "pow", "refr", "schlick", "lane_slots", "op_slots", "cull", "x_xform", "x_sphere", "x_box"]
 
