@@ -126,8 +126,11 @@ def main():
     # exact ray and event counts of this rank's share (untimed)
     st = scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT | rtx.F_COUNT_EVENTS, stream, True)
     rays_local = st.rays
-    fl_local = flops.frame_flops(st.events(), st.rays_primary, st.rays_shadow, len_lights(text))
-    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_secondary, fl_local], dtype=torch.float64, device=dev)
+    evs = st.events()
+    fl_local = flops.frame_flops(evs, st.rays_primary, st.rays_shadow, len_lights(text))
+    fl_exec = flops.executed_flops(evs, st.rays_primary, st.rays_shadow, len_lights(text))
+    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_secondary, fl_local, fl_exec,
+                           evs["cull"], evs["x_xform"], evs["xform"]], dtype=torch.float64, device=dev)
     if N > 1:
         dist.all_reduce(counts)
     rays_frame = int(counts[0] + counts[1] + counts[2])
@@ -172,6 +175,9 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
                          "kernel": "trace_shade_kernel", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_frame": float(counts[3]),
+                         "executed_f64_flops_per_frame": float(counts[4]),
+                         "node_visits": {"reference_defined": int(counts[7]), "f32_pre_tests": int(counts[5]),
+                                         "exact_f64_tests": int(counts[6])},
                          "frac_of_unfused_ceiling": achieved / flops.FP64_UNFUSED_PEAK_TFLOPS,
                          "note": "path is FP64-VALU bound (SURVEY.md 8d): no dense contraction (no MFMA), scene is "
                                  "L2-resident (HBM traffic = output image only); kernel_ms = slowest rank's average "

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
     }
 #define EV(e, n) do { if (COUNT) ev[e] += (n); } while (0)
 #ifdef RTX_TIMING
-    unsigned long long tm_ffwd = 0, tm_body = 0, tm_shade = 0, tm_other = 0, tm_mark = __builtin_amdgcn_s_memtime();
+    unsigned long long tm_ffwd = 0, tm_body = 0, tm_shade = 0, tm_other = 0, tm_prep = 0, tm_light = 0, tm_mark = __builtin_amdgcn_s_memtime();
 #define TM(acc) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_mark; tm_mark = now_; } while (0)
 #else
 #define TM(acc) do { } while (0)
@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 light_k = 0;
                 if (n_lights == 0) lights_done = true;
             }
+            TM(tm_prep);
         } else if (mode == MODE_SHADOW) {
             // ---- lighting for light_k (material.rs:54-81) with the shadow answer of this trace
             const bool in_shadow = have && best_t < shadow_dist;
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             sr = sr + cr; sg = sg + cg; sb = sb + cb;
             light_k++;
             if (light_k >= n_lights) lights_done = true;
+            TM(tm_light);
         }
 
         if (mode != MODE_DONE && !returning && !lights_done) {
@@ -762,6 +764,8 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         atomicAdd(&counters[RTX_CNT_EV0 + 19], tm_body);
         atomicAdd(&counters[RTX_CNT_EV0 + 20], tm_shade);
         atomicAdd(&counters[RTX_CNT_EV0 + 21], tm_other);
+        atomicAdd(&counters[RTX_CNT_EV0 + 22], tm_prep);
+        atomicAdd(&counters[RTX_CNT_EV0 + 23], tm_light);
     }
 #endif
     // ---- ray / event counters: one atomic per wave per counter

@@ -37,5 +37,14 @@ def frame_flops(ev, rays_primary, rays_shadow, n_lights):
     return f
 
 
+def executed_flops(ev, rays_primary, rays_shadow, n_lights):
+    """f64 flops the kernel actually issued: the conservative f32 bounding-sphere pre-test (rtx_kernel.hip
+    cull_miss, not counted here: it is f32) removes most exact node tests, so this is <= frame_flops()."""
+    f = frame_flops(ev, rays_primary, rays_shadow, n_lights)
+    f -= X_RAY * ev["xform"] + SPH * ev["sphere"] + BOX * (ev["cube"] + ev["bounds"])
+    f += X_RAY * ev["x_xform"] + SPH * ev["x_sphere"] + BOX * ev["x_box"]
+    return f
+
+
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # 256 CU x 64 lanes x 2 (FMA) x 2.4 GHz (MI355X datasheet FP64 vector)
 FP64_UNFUSED_PEAK_TFLOPS = 39.3    # one flop per lane-issue: the ceiling for parity code (no a*b+c fusion)

@@ -21,6 +21,6 @@ for name in sys.argv[1:] or ["S2", "S3", "S4", "S5"]:
                op_packing=ev["xform"] / max(ev["op_slots"], 1),
                flops=flops.frame_flops(ev, st.rays_primary, st.rays_shadow, text.count("- add: light")),
                count_ms=st.kernel_ms, fast_ms=fast.kernel_ms,
-               timing=dict(cull=int(fast.ev[18]), exact=int(fast.ev[19]), shade=int(fast.ev[20]), other=int(fast.ev[21])))
+               timing=dict(cull=int(fast.ev[18]), exact=int(fast.ev[19]), shade=int(fast.ev[20]), other=int(fast.ev[21]), prep=int(fast.ev[22]), light=int(fast.ev[23])))
     print(json.dumps(out))
     sc.close()
