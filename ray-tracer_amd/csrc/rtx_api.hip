@@ -14,6 +14,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
+#include "rtx_math.h"
 
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
@@ -30,6 +31,9 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 3: r = __builtin_floor(x); break;
         case 4: r = __builtin_round(x); break;
         case 5: r = __builtin_fmax(x, y); break;
+        case 7: r = rtx_div1(x, y); break;                                    // shared-reciprocal division (rtx_math.h)
+        case 8: { double q0, q1, q2; rtx_div3(0.0, x, -x, y, q0, q1, q2); r = ((q0 == 0.0 || q0 != q0) && (q2 == -q1 || q1 != q1)) ? q1 : __builtin_nan(""); break; }
+        case 9: { double q0, q1; rtx_div2(x, x * 0.75, y, q0, q1); r = (q1 == (x * 0.75) / y || q1 != q1) ? q0 : __builtin_nan(""); break; }
         default: r = __builtin_fmin(x, y); break;
     }
     out[i] = r;
@@ -400,7 +404,7 @@ void rtx_scene_destroy(rtx_scene* s) {
 }
 
 int rtx_debug_math(rtx_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out) {
-    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 6) return RTX_E_INVALID;
+    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 9) return RTX_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)n * sizeof(double);

@@ -26,6 +26,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
+#include "rtx_math.h"
 
 #define DI __device__ __forceinline__
 #define AS4 __attribute__((address_space(4)))
@@ -36,7 +37,7 @@ struct V3 { double x, y, z; };
 DI V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 DI V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 DI V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-DI V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+DI V3 operator/(V3 a, double s) { V3 q; rtx_div3(a.x, a.y, a.z, s, q.x, q.y, q.z); return q; }   // shared reciprocal, same bits
 DI V3 neg(V3 a) { return {-a.x, -a.y, -a.z}; }
 // nalgebra 3-vector dot: (a0*b0 + a1*b1) + a2*b2
 DI double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -82,8 +83,7 @@ DI void check_axis(double origin, double direction, double mn, double mx, double
     double tmax_n = mx - origin;
     double a, b;
     if (__builtin_fabs(direction) >= 1e-12) {
-        a = tmin_n / direction;
-        b = tmax_n / direction;
+        rtx_div2(tmin_n, tmax_n, direction, a, b);
     } else {
         a = tmin_n * INF;
         b = tmax_n * INF;
@@ -374,12 +374,11 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                             double disc = b * b - 4.0 * a * c;
                             if (!(disc < 0.0)) {
                                 double sq = __builtin_sqrt(disc);
-                                t0 = (-b - sq) / (2.0 * a);
-                                t1 = (-b + sq) / (2.0 * a);
+                                rtx_div2(-b - sq, -b + sq, 2.0 * a, t0, t1);
                                 k = 2;
                             }
                         } else if (k1 == OPK_PLANE) {             // plane.rs:16-23
-                            if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
+                            if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = rtx_div1(-lo.y, ld.y); k = 1; }
                         } else {                                  // cube.rs:18-31
                             EV(RTX_EV_X_BOX, 1);
                             if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
@@ -650,7 +649,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             V3 fo = {0, 0, 0}, fd = {0, 0, 0};
             if (remaining != 0 && !(transp == 0.0)) {                             // world.rs:167-170
                 EV(RTX_EV_REFR, 1);
-                const double n_ratio = n1 / n2;
+                const double n_ratio = rtx_div1(n1, n2);
                 const double cos_i = dot3(eyev, nv);
                 const double sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
                 if (!(sin2_t > 1.0)) {
@@ -667,14 +666,14 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 double cosv = dot3(eyev, nv);
                 bool tir = false;
                 if (n1 > n2) {
-                    const double n = n1 / n2;
+                    const double n = rtx_div1(n1, n2);
                     const double s2 = n * n * (1.0 - cosv * cosv);
                     if (s2 > 1.0) tir = true;
                     else cosv = __builtin_sqrt(1.0 - s2);
                 }
                 if (tir) R = 1.0;
                 else {
-                    const double q = (n1 - n2) / (n1 + n2);
+                    const double q = rtx_div1(n1 - n2, n1 + n2);
                     const double r0 = q * q;
                     const double x = 1.0 - cosv;
                     const double x2 = x * x;
