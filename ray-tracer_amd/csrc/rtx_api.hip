@@ -14,7 +14,6 @@
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
-#include "rtx_math.h"
 
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
@@ -31,9 +30,6 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 3: r = __builtin_floor(x); break;
         case 4: r = __builtin_round(x); break;
         case 5: r = __builtin_fmax(x, y); break;
-        case 7: r = rtx_div1(x, y); break;                                    // shared-reciprocal division (rtx_math.h)
-        case 8: { double q0, q1, q2; rtx_div3(0.0, x, -x, y, q0, q1, q2); r = ((q0 == 0.0 || q0 != q0) && (q2 == -q1 || q1 != q1)) ? q1 : __builtin_nan(""); break; }
-        case 9: { double q0, q1; rtx_div2(x, x * 0.75, y, q0, q1); r = (q1 == (x * 0.75) / y || q1 != q1) ? q0 : __builtin_nan(""); break; }
         default: r = __builtin_fmin(x, y); break;
     }
     out[i] = r;
@@ -201,10 +197,10 @@ struct Compiler {
             if ((size_t)si >= shapes.size()) shapes.resize(si + 1, ShapeRec{-1, 0, 0, 0});
             if (shapes[si].type != -1) { bad(RTX_E_INVALID, "duplicate shape index"); return 0; }
             ShapeRec s; s.type = kind; s.material = mi; s.path_begin = (int)paths.size();
-            for (int a : stack) paths.push_back(a);
-            paths.push_back(me);
-            s.path_len = (int)stack.size() + 1;
+            for (int a : stack) paths.push_back(a);          // ancestors only, root first
+            s.path_len = (int)stack.size();
             shapes[si] = s;
+            (void)me;
             return kind == RTX_NODE_PLANE ? 1 : 2;
         }
         if (kind != RTX_NODE_GROUP && kind != RTX_NODE_CSG) { bad(RTX_E_INVALID, "unknown node kind"); return 0; }
@@ -350,6 +346,8 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     std::vector<OpBody> bodies(cc.ops.size() + 1);
     std::memset(heads.data(), 0, heads.size() * sizeof(OpHead));
     std::memset(bodies.data(), 0, bodies.size() * sizeof(OpBody));
+    std::vector<HitRec> hits(cc.ops.size() + 1);
+    std::memset(hits.data(), 0, hits.size() * sizeof(HitRec));
     for (size_t i = 0; i < cc.ops.size(); i++) {
         const OpRec& o = cc.ops[i];
         OpHead& h = heads[i]; OpBody& b = bodies[i];
@@ -357,6 +355,13 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         h.skip = o.skip; h.shape = o.shape;
         std::memcpy(h.cull, o.cull, sizeof h.cull);
         std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33; std::memcpy(b.bounds, o.bounds, sizeof b.bounds);
+        b.div = (o.flags & OPF_DIV) ? 1 : 0;
+        if (o.kind <= OPK_CUBE) {
+            const ShapeRec& sr = cc.shapes[o.shape];
+            HitRec& hr = hits[i];
+            hr.shape = o.shape; hr.material = sr.material; hr.path_begin = sr.path_begin; hr.path_len = sr.path_len;
+            hr.ri = d->materials[sr.material].refractive_index; hr.type = sr.type;
+        }
     }
     // runs of consecutive shapes with the same level and list flag, at most 64 long (one candidate bit each)
     for (size_t i = cc.ops.size(); i-- > 0;) {
@@ -375,17 +380,17 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         for (size_t i = 0; i < heads.size(); i++)
             fprintf(stderr, "head %zu: info=%08x skip=%d shape=%d cull=%g %g %g %g\n", i, heads[i].info, heads[i].skip,
                     heads[i].shape, heads[i].cull[0], heads[i].cull[1], heads[i].cull[2], heads[i].cull[3]);
-    if ((rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, cc.shapes, &s->d_shapes)) ||
+    if ((rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
         (rc = upload(ctx, lights, &s->d_lights))) {
         rtx_scene_destroy(s);
         return rc;
     }
-    s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.shapes = (const ShapeRec*)s->d_shapes;
+    s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.hits = (const HitRec*)s->d_shapes;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
-    s->dev.n_levels = cc.max_container_level + 1;
+    s->dev.n_levels = cc.max_container_level + 2;   // slot 0 = world ray, slot L + 1 = local ray of the level-L container
     s->dev.has_csg = cc.has_csg ? 1 : 0; s->dev.has_transparency = transp ? 1 : 0;
     *out = s;
     return RTX_OK;
@@ -404,7 +409,7 @@ void rtx_scene_destroy(rtx_scene* s) {
 }
 
 int rtx_debug_math(rtx_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out) {
-    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 9) return RTX_E_INVALID;
+    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 6) return RTX_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)n * sizeof(double);

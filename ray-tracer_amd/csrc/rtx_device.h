@@ -32,7 +32,8 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
                        //   kind: OPK_*; flags: OPF_*; level: nesting depth (the ray to transform is the
                        //   local ray of level-1, 0 = world ray); clevel: container level inside a CSG root
     int32_t skip;      // BEGIN ops: index just past the matching END
-    int32_t shape;     // shape ops: ShapeIndex; CSG ops: operator
+    int32_t shape;     // CSG ops: operator (shape ops: ShapeIndex, informational; the kernel identifies a
+                       //   shape by its OP INDEX and reads HitRec[op] when it shades)
     int32_t run;       // shape ops: ops left in this run of consecutive same-level shapes (1..64), else 0
     float cull[4];     // bounding sphere in PARENT space: centre xyz, radius^2 (inflated); +inf = never cull
 };
@@ -44,15 +45,29 @@ struct OpBody {
     double inv[12];    // rows 0..2 of inverse(transform): inv[r*4+c]
     double w33;        // inverse(3,3)
     double bounds[6];  // containers: local bounds {min xyz, max xyz}
-    double pad[5];
+    int32_t div;       // w33 != 1.0 (copy of OPF_DIV, so shading needs no head load)
+    int32_t pad0;
+    double pad[4];
 };
 
-// per ShapeIndex
+// per ShapeIndex (host side only, while compiling)
 struct ShapeRec {
     int32_t type;        // OPK_SPHERE/PLANE/CUBE
     int32_t material;
     int32_t path_begin;  // into path_ops[]: op indices root -> shape (world_to_object chain)
     int32_t path_len;
+};
+
+// per OP INDEX of a shape op: everything shading needs to start from a hit (one 32-byte record, so
+// the hit's transform chain, material and refractive index are one load away from the op index)
+struct HitRec {
+    int32_t shape;       // ShapeIndex (what rtx_render reports as the hit id)
+    int32_t material;
+    int32_t path_begin;  // into path_ops[]: op indices of the ANCESTORS, root first (the shape's own op is
+    int32_t path_len;    //   not listed: it is the record's index); path_len = number of ancestors
+    double ri;           // material refractive index (world.rs:258-296 reads it per container)
+    int32_t type;        // OPK_SPHERE/PLANE/CUBE
+    int32_t pad;
 };
 
 struct MaterialRec {     // 208 bytes
@@ -69,7 +84,7 @@ struct LightRec { double pos[3]; double intensity[3]; };
 struct SceneDev {
     const OpHead* heads;      // n_ops + 2 entries (padding so the 2-deep prefetch never runs off the end)
     const OpBody* bodies;
-    const ShapeRec* shapes;
+    const HitRec* hits;       // n_ops + 1 entries, valid at shape ops
     const int32_t* path_ops;
     const MaterialRec* materials;
     const LightRec* lights;

@@ -20,13 +20,14 @@
 //  * recursion (world.rs:160,190) becomes a per-lane state machine with an explicit post-order
 //    frame stack of max_depth frames; every lane always traces *some* ray (radiance or shadow)
 //    in the shared traversal, so reflection/refraction divergence does not idle lanes.
-//  * local rays of enclosing containers live in an LDS stack (n_levels x 6 x 64 doubles).
+//  * the ray being traced and the local rays of the enclosing containers live in an LDS stack
+//    (n_levels x 6 x 64 doubles); the shading context that must survive a traversal is held to ~30
+//    registers and the frames in scratch carry only what a parent needs when a child returns.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
-#include "rtx_math.h"
 
 #define DI __device__ __forceinline__
 #define AS4 __attribute__((address_space(4)))
@@ -37,7 +38,7 @@ struct V3 { double x, y, z; };
 DI V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 DI V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 DI V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-DI V3 operator/(V3 a, double s) { V3 q; rtx_div3(a.x, a.y, a.z, s, q.x, q.y, q.z); return q; }   // shared reciprocal, same bits
+DI V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 DI V3 neg(V3 a) { return {-a.x, -a.y, -a.z}; }
 // nalgebra 3-vector dot: (a0*b0 + a1*b1) + a2*b2
 DI double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -46,7 +47,7 @@ DI V3 normalize3(V3 a) { return a / norm3(a); }            // unscale: component
 DI V3 reflect3(V3 v, V3 n) { return v - n * 2.0 * dot3(v, n); }   // geometry.rs:49-51
 
 #define INF __builtin_inf()
-#define LDS_LEVEL_DOUBLES 576          // per level: 6 x 64 doubles + 6 x 64 floats (f32 copy for the pre-test)
+#define LDS_SLOT_DOUBLES 384           // one ray per lane: 6 x 64 doubles
 #define CULL_KAPPA 1.0e-5f             // relative slack on |oc|^2 covering f32 rounding of the pre-test
 
 // Projective3 * Point3 with an affine matrix: (M3x3 p + t) / w33   (rows m[r*4+c])
@@ -83,7 +84,8 @@ DI void check_axis(double origin, double direction, double mn, double mx, double
     double tmax_n = mx - origin;
     double a, b;
     if (__builtin_fabs(direction) >= 1e-12) {
-        rtx_div2(tmin_n, tmax_n, direction, a, b);
+        a = tmin_n / direction;
+        b = tmax_n / direction;
     } else {
         a = tmin_n * INF;
         b = tmax_n * INF;
@@ -133,14 +135,21 @@ DI unsigned wave_sum(unsigned v) {
     return v;
 }
 
-struct Frame {           // one pending shade_hit (world.rs:127-149) waiting for its children
-    double sr, sg, sb;   // surface
-    double ar, ag, ab;   // reflected (already * reflective)
-    double ox, oy, oz, dx, dy, dz;   // refraction ray (world.rs:186-188)
-    double reflectance;
-    int32_t shape;
-    int32_t flags;       // 1: refraction ray pending, 2: waiting for the refracted child, 4: schlick mix
+// One shade_hit (world.rs:127-149) waiting for its children.  Frames live in scratch (indexed by the
+// per-lane stack pointer) and hold only what the parent needs when a child returns; the context of the
+// hit being shaded right now (point, normal, eye vector) stays in registers instead.
+struct Frame {
+    double s[3];         // surface; once the reflected child is back: surface + reflected [* reflectance]
+    double R, refl, transp;
+    double o2[3], d2[3]; // the refraction ray (world.rs:186-188) while the reflected child is traced
+    int32_t flags;       // FR_*
     int32_t remaining;   // the `remaining` this shade_hit was called with
+};
+enum {
+    FR_REFL = 1,         // the first child is the reflected ray (else: the only child is the refracted ray)
+    FR_REFR_PENDING = 2, // a refraction ray waits in o2/d2
+    FR_SECOND = 4,       // the child now being traced is that refraction ray
+    FR_BOTH = 8          // reflective > 0 && transparency > 0: Schlick mix (world.rs:142-145)
 };
 
 // One op head = 8 dwords fetched with a single scalar s_load_dwordx8 (constant address space) and
@@ -168,14 +177,25 @@ DI bool cull_miss(Head h, float fox, float foy, float foz, float fdx, float fdy,
     return lhs > rhs;                                                 // false on NaN
 }
 
+// world_to_object (object_store.rs:309-320): the ancestors root first, then the shape's own transform
+DI V3 to_object(const SceneDev& sc, const HitRec& hr, int hop, V3 p) {
+    for (int i = 0; i < hr.path_len; i++) {
+        const OpBody* xo = sc.bodies + sc.path_ops[hr.path_begin + i];
+        p = xf_point(xo->inv, xo->w33, xo->div != 0, p);
+    }
+    const OpBody* xo = sc.bodies + hop;
+    return xf_point(xo->inv, xo->w33, xo->div != 0, p);
+}
+
 enum { MODE_DONE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
 const uint32_t LBIT = 0x80000000u;
 
 }  // namespace
 
-// occupancy target (waves per SIMD): the kernel is instruction-issue bound, a wave issues at most one
-// instruction every 4 cycles, so more resident waves fill the issue slots; the register allocator
-// spills the long-lived shading context (live across, not inside, the traversal loop) to scratch.
+// occupancy target (waves per SIMD): the kernel waits on memory and on instruction issue, so resident
+// waves matter, but every register past the budget becomes scratch traffic that misses L2 (the scratch
+// of 4096 resident waves is far larger than the caches).  The shading state that has to survive a
+// traversal is therefore kept small: see the comments at the state variables below.
 #ifndef RTX_MIN_WAVES
 #define RTX_MIN_WAVES 4
 #endif
@@ -185,14 +205,11 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
                                                          unsigned long long* __restrict__ counters) {
-    extern __shared__ double lds_rays[];   // [level][6][64]
+    extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     const int tx = tile % rp.tiles_x, bl = tile / rp.tiles_x;
     const int band = rp.band_first + bl * rp.band_stride;
-    const int px = tx * RTX_TILE + (lane & 7);
-    const int py = band * RTX_TILE + (lane >> 3);
-    const bool valid = px < cam.hsize && py < cam.vsize;
 
     const AS4 OpHead* heads = (const AS4 OpHead*)(uintptr_t)sc.heads;
     const AS4 OpBody* bodies = (const AS4 OpBody*)(uintptr_t)sc.bodies;
@@ -214,32 +231,42 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
 #define TM(acc) do { } while (0)
 #endif
 
-    // ---- Camera::ray_for_pixel (camera.rs:56-69)
-    V3 ro, rd;
+    int mode;
+    // ---- Camera::ray_for_pixel (camera.rs:56-69); the ray goes to LDS slot 0
     {
+        const int px = tx * RTX_TILE + (lane & 7);
+        const int py = band * RTX_TILE + (lane >> 3);
+        mode = (px < cam.hsize && py < cam.vsize) ? MODE_RADIANCE : MODE_DONE;
         double xoffset = ((double)px + 0.5) * cam.pixel_size;
         double yoffset = ((double)py + 0.5) * cam.pixel_size;
         double world_x = cam.half_width - xoffset;
         double world_y = cam.half_height - yoffset;
         V3 pixel = xf_point(cam.inv, cam.w33, cam.div != 0, V3{world_x, world_y, -1.0});
-        ro = V3{cam.origin[0], cam.origin[1], cam.origin[2]};
-        rd = normalize3(pixel - ro);
+        V3 ro = V3{cam.origin[0], cam.origin[1], cam.origin[2]};
+        V3 rd = normalize3(pixel - ro);
+        double* s = lds_rays + lane;
+        s[0] = ro.x; s[64] = ro.y; s[128] = ro.z; s[192] = rd.x; s[256] = rd.y; s[320] = rd.z;
     }
+    // Canvas::write_pixel + Color::to_rgb (canvas.rs:31-33, color.rs:40-48), the moment a lane's colour is final
+    auto write_pixel = [&](double r, double g, double b) {
+        const int px = tx * RTX_TILE + (lane & 7);
+        const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : (band * RTX_TILE + (lane >> 3));
+        const size_t idx = (size_t)row * cam.hsize + px;
+        rgb[idx * 3 + 0] = quantise(r);
+        rgb[idx * 3 + 1] = quantise(g);
+        rgb[idx * 3 + 2] = quantise(b);
+    };
 
-    int mode = valid ? MODE_RADIANCE : MODE_DONE;
-    int remaining = rp.max_depth;
-    int sp = 0;
+    // ---- state that survives a traversal (everything else is rebuilt or re-read):
+    int remaining = rp.max_depth;         // budget of the color_at call being traced
+    int sp = 0;                           // frames below sp wait for children
     Frame frames[RTX_MAX_DEPTH];
     bool primary = true;
-    int primary_id = -1;
-    double resr = 0.0, resg = 0.0, resb = 0.0;
-
-    // hit context, live across the shadow traces of one shade_hit
+    // the hit being shaded while its shadow rays are traced (PreparedComputations, world.rs:225-256)
     V3 hp = {0, 0, 0}, eyev = {0, 0, 0}, nv = {0, 0, 0};
-    double n1 = 1.0, n2 = 1.0;
-    int hshape = -1;
-    double sr = 0.0, sg = 0.0, sb = 0.0;       // surface accumulator
-    double pcr = 0.0, pcg = 0.0, pcb = 0.0;    // pattern colour at the hit
+    int hop = 0;                          // op index of the hit shape
+    int hmat = 0;                         // its material
+    int n1op = -1, n2op = -1;             // ops whose refractive indices are n1 / n2 (-1: vacuum, 1.0)
     int light_k = 0;
     double shadow_dist = 0.0;
 
@@ -255,8 +282,9 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         else if (mode == MODE_SHADOW) n_shadow++;
         EV(RTX_EV_LANE_SLOTS, 1);         // every lane, busy or not: 64 per wave trace
 
-        bool have = false; double best_t = 0.0; int best_shape = -1; bool best_inside = false;
-        double c1t = -INF, c2t = -INF; int c1s = -1, c2s = -1;     // refractive containers (§9.3)
+        // running state instead of a sorted hit list; shapes are identified by op index
+        double best_t = 0.0; int best_op = -1; bool best_inside = false;
+        double c1t = -INF, c2t = -INF; int c1s = -1, c2s = -1;     // refractive containers
         int resume_at = (mode != MODE_DONE) ? 0 : n_ops;
         int cnt = 0;                      // CSG list length
         uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
@@ -267,10 +295,10 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             if (k == 0) return;
             const bool nn0 = t0 >= 0.0;
             if (nn0) {
-                if (!have || t0 < best_t) { have = true; best_t = t0; best_shape = shape; best_inside = false; }
+                if (best_op < 0 || t0 < best_t) { best_t = t0; best_op = shape; best_inside = false; }
             } else {
                 if (k == 2 && t1 >= 0.0) {
-                    if (!have || t1 < best_t) { have = true; best_t = t1; best_shape = shape; best_inside = true; }
+                    if (best_op < 0 || t1 < best_t) { best_t = t1; best_op = shape; best_inside = true; }
                 }
                 // exactly one negative entry -> the shape is an open container behind the origin
                 if (k == 1 || t1 >= 0.0) {
@@ -281,30 +309,20 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         };
 
         // parent-space ray of the level being walked: f64 for the exact tests, an f32 copy for the
-        // conservative bounding-sphere pre-test.  Level 0 = the world ray; deeper levels are
-        // re-read from the LDS stack when the walk returns to them.
-        V3 po = ro, pd = rd;
-        float fox = (float)ro.x, foy = (float)ro.y, foz = (float)ro.z;
-        float fdx = (float)rd.x, fdy = (float)rd.y, fdz = (float)rd.z;
-        float fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
-        int cached_level = 0;
-
-        // reload the parent-space ray when the walk changes level (uniform)
+        // conservative bounding-sphere pre-test; (re)read from the LDS stack when the walk changes level
+        V3 po, pd;
+        float fox, foy, foz, fdx, fdy, fdz, fdd;
+        int cached_level = -1;
         auto sync_level = [&](int level) {
             if (level == cached_level) return;
-            if (level == 0) {
-                po = ro; pd = rd;
-                fox = (float)ro.x; foy = (float)ro.y; foz = (float)ro.z;
-                fdx = (float)rd.x; fdy = (float)rd.y; fdz = (float)rd.z;
-            } else {
-                const double* s = lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + lane;
-                po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
-                const float* f = (const float*)(lds_rays + (level - 1) * LDS_LEVEL_DOUBLES + 384) + lane;
-                fox = f[0]; foy = f[64]; foz = f[128]; fdx = f[192]; fdy = f[256]; fdz = f[320];
-            }
+            const double* s = lds_rays + level * LDS_SLOT_DOUBLES + lane;
+            po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
+            fox = (float)po.x; foy = (float)po.y; foz = (float)po.z;
+            fdx = (float)pd.x; fdy = (float)pd.y; fdz = (float)pd.z;
             fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
             cached_level = level;
         };
+        sync_level(0);
 
         int cur = 0;
         while (cur < n_ops) {
@@ -357,12 +375,9 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         const int i = __builtin_ctzll(cand);
                         cand &= cand - 1;
                         const int idx = cur + i;
-                        const OpHead* gh = sc.heads + idx;
                         const OpBody* gb = sc.bodies + idx;
-                        const uint32_t info = gh->info;
-                        const int k1 = OPH_KIND(info);
-                        const int shape = gh->shape;
-                        V3 lo = xf_point(gb->inv, gb->w33, (OPH_FLAGS(info) & OPF_DIV) != 0, po);
+                        const int k1 = OPH_KIND(sc.heads[idx].info);
+                        V3 lo = xf_point(gb->inv, gb->w33, gb->div != 0, po);
                         V3 ld = xf_vector(gb->inv, pd);
                         EV(RTX_EV_X_XFORM, 1);
                         int k = 0; double t0 = 0.0, t1 = 0.0;
@@ -374,23 +389,24 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                             double disc = b * b - 4.0 * a * c;
                             if (!(disc < 0.0)) {
                                 double sq = __builtin_sqrt(disc);
-                                rtx_div2(-b - sq, -b + sq, 2.0 * a, t0, t1);
+                                t0 = (-b - sq) / (2.0 * a);
+                                t1 = (-b + sq) / (2.0 * a);
                                 k = 2;
                             }
                         } else if (k1 == OPK_PLANE) {             // plane.rs:16-23
-                            if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = rtx_div1(-lo.y, ld.y); k = 1; }
+                            if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
                         } else {                                  // cube.rs:18-31
                             EV(RTX_EV_X_BOX, 1);
                             if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
                         }
                         if (CSG && (flags & OPF_LIST)) {
                             if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
-                            if (k >= 1) { lt[cnt] = t0; ls[cnt] = (uint32_t)shape; cnt++; }
-                            if (k == 2) { lt[cnt] = t1; ls[cnt] = (uint32_t)shape; cnt++; }
+                            if (k >= 1) { lt[cnt] = t0; ls[cnt] = (uint32_t)idx; cnt++; }
+                            if (k == 2) { lt[cnt] = t1; ls[cnt] = (uint32_t)idx; cnt++; }
                         } else {
-                            feed(k, t0, t1, shape);
+                            feed(k, t0, t1, idx);
                             // is_shadowed (world.rs:203-206): any 0 <= t < distance decides
-                            if (is_shadow && !rp.no_early_out && have && best_t < shadow_dist) { resume_at = n_ops; cand = 0; }
+                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; cand = 0; }
                         }
                     }
                 }
@@ -424,8 +440,6 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                     if (!__any(pass)) {
                         next = H_SKIP(h);
                     } else {
-                        double* s = lds_rays + level * LDS_LEVEL_DOUBLES + lane;
-                        float* f = (float*)(lds_rays + level * LDS_LEVEL_DOUBLES + 384) + lane;
                         // the children (level + 1) walk in this node's space
                         po = lo; pd = ld;
                         fox = (float)lo.x; foy = (float)lo.y; foz = (float)lo.z;
@@ -433,9 +447,9 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
                         cached_level = level + 1;
                         if (pass) {
+                            double* s = lds_rays + (level + 1) * LDS_SLOT_DOUBLES + lane;
                             s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
                             s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
-                            f[0] = fox; f[64] = foy; f[128] = foz; f[192] = fdx; f[256] = fdy; f[320] = fdz;
                             if (CSG && (flags & OPF_LIST)) {
                                 const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
                                 starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                                 for (int j = 0; j < cnt; j++)
                                     if ((int)(ls[j] & ~LBIT) == shape && !(lt[j] >= 0.0)) negs++;
                                 if (t >= 0.0) {
-                                    if (!have || t < best_t) { have = true; best_t = t; best_shape = shape; best_inside = (negs == 1); }
+                                    if (best_op < 0 || t < best_t) { best_t = t; best_op = shape; best_inside = (negs == 1); }
                                     break;      // later entries are larger
                                 } else if (negs == 1) {
                                     if (t >= c1t) { c2t = c1t; c2s = c1s; c1t = t; c1s = shape; }
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                                 }
                             }
                             cnt = 0;
-                            if (is_shadow && !rp.no_early_out && have && best_t < shadow_dist) resume_at = n_ops;
+                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) resume_at = n_ops;
                         }
                     }
                 }
@@ -522,29 +536,38 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         bool returning = false;                 // lane has a finished colour to hand to its parent frame
         double rr = 0.0, rg = 0.0, rb = 0.0;
         bool lights_done = false;
+        double sr = 0.0, sg = 0.0, sb = 0.0;    // surface colour of the hit being shaded (this iteration's view)
+        bool newray = false;                    // lane launches (nro, nrd) next
+        V3 nro = {0, 0, 0}, nrd = {0, 0, 0};
 
         if (mode == MODE_RADIANCE) {
-            if (primary) { primary_id = have ? best_shape : -1; primary = false; }
-            if (!have) {                        // world.rs:107
+            if (primary) {
+                primary = false;
+                if (hit_out) {
+                    const int px = tx * RTX_TILE + (lane & 7);
+                    const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : (band * RTX_TILE + (lane >> 3));
+                    hit_out[(size_t)row * cam.hsize + px] = best_op >= 0 ? sc.hits[best_op].shape : -1;
+                }
+            }
+            if (best_op < 0) {                  // world.rs:107
                 returning = true;
             } else {
                 // ---- PreparedComputations::new (world.rs:225-256)
                 EV(RTX_EV_HIT, 1);
-                hshape = best_shape;
-                hp = ro + rd * best_t;          // rays.rs:17-19 (t * direction is commutative)
-                eyev = neg(rd);
-                const ShapeRec srec = sc.shapes[hshape];
-                EV(RTX_EV_LEVELS, srec.path_len);
-                // world_to_object (object_store.rs:309-320): root -> shape
-                V3 objp = hp;
-                for (int i = 0; i < srec.path_len; i++) {
-                    const int pi = sc.path_ops[srec.path_begin + i];
-                    const OpBody* xo = sc.bodies + pi;
-                    objp = xf_point(xo->inv, xo->w33, (OPH_FLAGS(sc.heads[pi].info) & OPF_DIV) != 0, objp);
+                hop = best_op;
+                const HitRec hr = sc.hits[hop];
+                hmat = hr.material;
+                EV(RTX_EV_LEVELS, hr.path_len + 1);
+                {
+                    const double* w = lds_rays + lane;      // the ray just traced
+                    const V3 wo = {w[0], w[64], w[128]}, wd = {w[192], w[256], w[320]};
+                    hp = wo + wd * best_t;      // rays.rs:17-19 (t * direction is commutative)
+                    eyev = neg(wd);
                 }
+                const V3 objp = to_object(sc, hr, hop, hp);
                 V3 ln;
-                if (srec.type == OPK_SPHERE) ln = objp;                          // sphere.rs:34-36
-                else if (srec.type == OPK_PLANE) ln = V3{0.0, 1.0, 0.0};          // plane.rs:25-27
+                if (hr.type == OPK_SPHERE) ln = objp;                            // sphere.rs:34-36
+                else if (hr.type == OPK_PLANE) ln = V3{0.0, 1.0, 0.0};            // plane.rs:25-27
                 else {                                                            // cube.rs:33-47
                     double ax = __builtin_fabs(objp.x), ay = __builtin_fabs(objp.y), az = __builtin_fabs(objp.z);
                     double maxc = __builtin_fmax(__builtin_fmax(ax, ay), az);
@@ -553,57 +576,52 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                     else ln = V3{0.0, 0.0, objp.z};
                 }
                 // normal_to_world (object_store.rs:331-349): shape -> root, normalised per level
-                for (int i = srec.path_len - 1; i >= 0; i--) {
-                    const OpBody* xo = sc.bodies + sc.path_ops[srec.path_begin + i];
+                ln = normalize3(xf_normal((sc.bodies + hop)->inv, ln));
+                for (int i = hr.path_len - 1; i >= 0; i--) {
+                    const OpBody* xo = sc.bodies + sc.path_ops[hr.path_begin + i];
                     ln = normalize3(xf_normal(xo->inv, ln));
                 }
                 nv = ln;
                 if (dot3(nv, eyev) < 0.0) nv = neg(nv);                           // world.rs:232-237
-                // get_refractive_indices_at (world.rs:258-296) from the running state (§9.3)
-                {
-                    const MaterialRec* mats = sc.materials;
-                    n1 = (c1s >= 0) ? mats[sc.shapes[c1s].material].refractive_index : 1.0;
-                    if (c1s >= 0 && best_inside) {
-                        const int s2 = (hshape == c1s) ? c2s : c1s;
-                        n2 = (s2 >= 0) ? mats[sc.shapes[s2].material].refractive_index : 1.0;
-                    } else {
-                        n2 = mats[srec.material].refractive_index;
-                    }
-                }
-                // pattern colour (object_store.rs:293-299); same point for every light
-                {
-                    const MaterialRec* m = sc.materials + srec.material;
-                    const int pk = m->kind;
-                    V3 a = {m->a[0], m->a[1], m->a[2]};
-                    if (pk == RTX_PAT_PLAIN) { pcr = a.x; pcg = a.y; pcb = a.z; }
-                    else {
-                        V3 pp = xf_point(m->pinv, m->pw33, m->pdiv != 0, objp);
-                        V3 b = {m->b[0], m->b[1], m->b[2]};
-                        if (pk == RTX_PAT_TEST) { pcr = pp.x; pcg = pp.y; pcb = pp.z; }
-                        else if (pk == RTX_PAT_GRADIENT) {                         // patterns.rs:144-151
-                            double fr = pp.x - __builtin_floor(pp.x);
-                            pcr = a.x + (b.x - a.x) * fr; pcg = a.y + (b.y - a.y) * fr; pcb = a.z + (b.z - a.z) * fr;
-                        } else {
-                            int odd;
-                            if (pk == RTX_PAT_STRIPES) odd = floor_parity(pp.x);                                    // :96-104
-                            else if (pk == RTX_PAT_RINGS) odd = floor_parity(__builtin_sqrt(pp.x * pp.x + pp.z * pp.z));   // :112-121
-                            else odd = floor_parity(pp.x) ^ floor_parity(pp.y) ^ floor_parity(pp.z);                // :128-136
-                            V3 c = odd ? b : a;
-                            pcr = c.x; pcg = c.y; pcb = c.z;
-                        }
-                    }
-                }
-                sr = 0.0; sg = 0.0; sb = 0.0;    // Sum::sum folds from black (color.rs:69-73)
+                // get_refractive_indices_at (world.rs:258-296) from the running state: remember
+                // WHICH shapes supply n1 / n2; the indices themselves are read when the children are decided
+                n1op = c1s;
+                n2op = (c1s >= 0 && best_inside) ? ((hop == c1s) ? c2s : c1s) : hop;
                 light_k = 0;
                 if (n_lights == 0) lights_done = true;
             }
             TM(tm_prep);
         } else if (mode == MODE_SHADOW) {
             // ---- lighting for light_k (material.rs:54-81) with the shadow answer of this trace
-            const bool in_shadow = have && best_t < shadow_dist;
+            const bool in_shadow = best_op >= 0 && best_t < shadow_dist;
             EV(RTX_EV_LIGHT, 1);
             const LightRec* L = sc.lights + light_k;
-            const MaterialRec* m = sc.materials + sc.shapes[hshape].material;
+            const MaterialRec* m = sc.materials + hmat;
+            // pattern colour at the hit (object_store.rs:293-299), evaluated per light like the reference
+            double pcr, pcg, pcb;
+            {
+                const int pk = m->kind;
+                V3 a = {m->a[0], m->a[1], m->a[2]};
+                if (pk == RTX_PAT_PLAIN) { pcr = a.x; pcg = a.y; pcb = a.z; }
+                else {
+                    const HitRec hr = sc.hits[hop];
+                    const V3 objp = to_object(sc, hr, hop, hp);
+                    V3 pp = xf_point(m->pinv, m->pw33, m->pdiv != 0, objp);
+                    V3 b = {m->b[0], m->b[1], m->b[2]};
+                    if (pk == RTX_PAT_TEST) { pcr = pp.x; pcg = pp.y; pcb = pp.z; }
+                    else if (pk == RTX_PAT_GRADIENT) {                         // patterns.rs:144-151
+                        double fr = pp.x - __builtin_floor(pp.x);
+                        pcr = a.x + (b.x - a.x) * fr; pcg = a.y + (b.y - a.y) * fr; pcb = a.z + (b.z - a.z) * fr;
+                    } else {
+                        int odd;
+                        if (pk == RTX_PAT_STRIPES) odd = floor_parity(pp.x);                                    // :96-104
+                        else if (pk == RTX_PAT_RINGS) odd = floor_parity(__builtin_sqrt(pp.x * pp.x + pp.z * pp.z));   // :112-121
+                        else odd = floor_parity(pp.x) ^ floor_parity(pp.y) ^ floor_parity(pp.z);                // :128-136
+                        V3 c = odd ? b : a;
+                        pcr = c.x; pcg = c.y; pcb = c.z;
+                    }
+                }
+            }
             const double ir = L->intensity[0], ig = L->intensity[1], ib = L->intensity[2];
             const double er = pcr * ir, eg = pcg * ig, eb = pcb * ib;             // effective_color
             V3 lightv = normalize3(V3{L->pos[0], L->pos[1], L->pos[2]} - hp);
@@ -624,9 +642,12 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 }
             }
             cr = cr + dr + spr; cg = cg + dg + spg; cb = cb + db + spb;           // ambient + diffuse + specular
+            // Sum::sum folds from black (color.rs:69-73); the partial sum waits in the frame slot being built
+            if (light_k > 0) { const Frame& f = frames[sp]; sr = f.s[0]; sg = f.s[1]; sb = f.s[2]; }
             sr = sr + cr; sg = sg + cg; sb = sb + cb;
             light_k++;
             if (light_k >= n_lights) lights_done = true;
+            else { Frame& f = frames[sp]; f.s[0] = sr; f.s[1] = sg; f.s[2] = sb; }
             TM(tm_light);
         }
 
@@ -636,48 +657,57 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             V3 over = hp + nv * 1e-10;                                            // world.rs:238-239
             V3 v = V3{L->pos[0], L->pos[1], L->pos[2]} - over;
             shadow_dist = norm3(v);
-            ro = over; rd = v / shadow_dist;                                      // normalize() recomputes the same norm
+            nro = over; nrd = v / shadow_dist;                                    // normalize() recomputes the same norm
+            newray = true;
             mode = MODE_SHADOW;
         }
 
         if (lights_done) {
             // ---- rest of shade_hit (world.rs:138-148): decide the children
-            const MaterialRec* m = sc.materials + sc.shapes[hshape].material;
+            const MaterialRec* m = sc.materials + hmat;
             const double refl = m->reflective, transp = m->transparency;
             const bool do_refl = remaining != 0 && !(refl == 0.0);                // world.rs:155
+            const bool want_refr = remaining != 0 && !(transp == 0.0);            // world.rs:167-170
+            const bool both = refl > 0.0 && transp > 0.0;
             bool do_refr = false;
             V3 fo = {0, 0, 0}, fd = {0, 0, 0};
-            if (remaining != 0 && !(transp == 0.0)) {                             // world.rs:167-170
-                EV(RTX_EV_REFR, 1);
-                const double n_ratio = rtx_div1(n1, n2);
-                const double cos_i = dot3(eyev, nv);
-                const double sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
-                if (!(sin2_t > 1.0)) {
-                    const double cos_t = __builtin_sqrt(1.0 - sin2_t);
-                    fd = nv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
-                    fo = hp - nv * 1e-10;                                         // under_point
-                    do_refr = true;
-                }
-            }
-            const bool both = refl > 0.0 && transp > 0.0;
             double R = 0.0;
-            if (both) {                                                           // schlick (world.rs:304-323)
-                EV(RTX_EV_SCHLICK, 1);
-                double cosv = dot3(eyev, nv);
-                bool tir = false;
-                if (n1 > n2) {
-                    const double n = rtx_div1(n1, n2);
-                    const double s2 = n * n * (1.0 - cosv * cosv);
-                    if (s2 > 1.0) tir = true;
-                    else cosv = __builtin_sqrt(1.0 - s2);
+            if (want_refr || both) {
+                // refracted_color (world.rs:174-188) and schlick (world.rs:304-323) evaluate the same
+                // n1/n2, cos_i, sin2_t and cos_t expressions: computed once, same bits
+                const double n1 = (n1op >= 0) ? sc.hits[n1op].ri : 1.0;
+                const double n2 = (n2op >= 0) ? sc.hits[n2op].ri : 1.0;
+                const double cos_i = dot3(eyev, nv);
+                double sin2_t = 0.0, cos_t = 0.0, n_ratio = 0.0;
+                if (want_refr || n1 > n2) {
+                    n_ratio = n1 / n2;
+                    sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
+                    if (!(sin2_t > 1.0)) cos_t = __builtin_sqrt(1.0 - sin2_t);
                 }
-                if (tir) R = 1.0;
-                else {
-                    const double q = rtx_div1(n1 - n2, n1 + n2);
-                    const double r0 = q * q;
-                    const double x = 1.0 - cosv;
-                    const double x2 = x * x;
-                    R = r0 + (1.0 - r0) * (x * (x2 * x2));
+                if (want_refr) {
+                    EV(RTX_EV_REFR, 1);
+                    if (!(sin2_t > 1.0)) {
+                        fd = nv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+                        fo = hp - nv * 1e-10;                                     // under_point
+                        do_refr = true;
+                    }
+                }
+                if (both) {
+                    EV(RTX_EV_SCHLICK, 1);
+                    double cosv = cos_i;
+                    bool tir = false;
+                    if (n1 > n2) {
+                        if (sin2_t > 1.0) tir = true;
+                        else cosv = cos_t;
+                    }
+                    if (tir) R = 1.0;
+                    else {
+                        const double q = (n1 - n2) / (n1 + n2);
+                        const double r0 = q * q;
+                        const double x = 1.0 - cosv;
+                        const double x2 = x * x;
+                        R = r0 + (1.0 - r0) * (x * (x2 * x2));
+                    }
                 }
             }
             if (!do_refl && !do_refr) {
@@ -686,20 +716,19 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 returning = true;
             } else {
                 Frame& f = frames[sp];
-                f.sr = sr; f.sg = sg; f.sb = sb;
-                f.ar = 0.0; f.ag = 0.0; f.ab = 0.0;
-                f.ox = fo.x; f.oy = fo.y; f.oz = fo.z; f.dx = fd.x; f.dy = fd.y; f.dz = fd.z;
-                f.reflectance = R;
-                f.shape = hshape;
+                f.s[0] = sr; f.s[1] = sg; f.s[2] = sb;
+                f.R = R; f.refl = refl; f.transp = transp;
                 f.remaining = remaining;
                 if (do_refl) {
-                    f.flags = (do_refr ? 1 : 0) | (both ? 4 : 0);
-                    V3 over = hp + nv * 1e-10;
-                    ro = over; rd = reflect3(neg(eyev), nv);                      // reflectv (world.rs:251)
+                    f.flags = FR_REFL | (do_refr ? FR_REFR_PENDING : 0) | (both ? FR_BOTH : 0);
+                    if (do_refr) { f.o2[0] = fo.x; f.o2[1] = fo.y; f.o2[2] = fo.z; f.d2[0] = fd.x; f.d2[1] = fd.y; f.d2[2] = fd.z; }
+                    nro = hp + nv * 1e-10;                                        // over_point
+                    nrd = reflect3(neg(eyev), nv);                                // reflectv (world.rs:251)
                 } else {
-                    f.flags = 2 | (both ? 4 : 0);
-                    ro = fo; rd = fd;
+                    f.flags = both ? FR_BOTH : 0;
+                    nro = fo; nrd = fd;
                 }
+                newray = true;
                 sp++;
                 remaining = remaining - 1;
                 mode = MODE_RADIANCE;
@@ -709,52 +738,55 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         // ---- unwind: hand finished colours to the waiting frames (post-order)
         while (returning) {
             if (sp == 0) {
-                resr = rr; resg = rg; resb = rb;
+                write_pixel(rr, rg, rb);
                 mode = MODE_DONE;
                 returning = false;
             } else {
                 Frame& f = frames[sp - 1];
-                const MaterialRec* m = sc.materials + sc.shapes[f.shape].material;
-                if (!(f.flags & 2)) {
-                    // reflected child finished (world.rs:160-162)
-                    const double refl = m->reflective;
-                    f.ar = rr * refl; f.ag = rg * refl; f.ab = rb * refl;
-                    if (f.flags & 1) {
-                        f.flags |= 2;
-                        ro = V3{f.ox, f.oy, f.oz}; rd = V3{f.dx, f.dy, f.dz};
+                const int fl = f.flags;
+                const double R = f.R;
+                double s0 = f.s[0], s1 = f.s[1], s2 = f.s[2];
+                if (fl & FR_SECOND) {
+                    // refracted child finished (world.rs:190-192); f.s already holds surface + reflected [* R]
+                    const double transp = f.transp;
+                    rr = rr * transp; rg = rg * transp; rb = rb * transp;
+                    if (fl & FR_BOTH) { rr = s0 + rr * (1.0 - R); rg = s1 + rg * (1.0 - R); rb = s2 + rb * (1.0 - R); }
+                    else { rr = s0 + rr; rg = s1 + rg; rb = s2 + rb; }
+                } else if (fl & FR_REFL) {
+                    // reflected child finished (world.rs:160-162): surface + reflected [* reflectance] ...
+                    const double refl = f.refl;
+                    double ar = rr * refl, ag = rg * refl, ab = rb * refl;
+                    if (fl & FR_BOTH) { s0 = s0 + ar * R; s1 = s1 + ag * R; s2 = s2 + ab * R; }
+                    else { s0 = s0 + ar; s1 = s1 + ag; s2 = s2 + ab; }
+                    if (fl & FR_REFR_PENDING) {
+                        f.s[0] = s0; f.s[1] = s1; f.s[2] = s2;
+                        f.flags = fl | FR_SECOND;
+                        nro = V3{f.o2[0], f.o2[1], f.o2[2]}; nrd = V3{f.d2[0], f.d2[1], f.d2[2]};
+                        newray = true;
                         remaining = f.remaining - 1;
                         mode = MODE_RADIANCE;
                         returning = false;
                         continue;
                     }
-                    rr = 0.0; rg = 0.0; rb = 0.0;        // refracted = black
+                    // ... + refracted, which is black here
+                    if (fl & FR_BOTH) { rr = s0 + 0.0 * (1.0 - R); rg = s1 + 0.0 * (1.0 - R); rb = s2 + 0.0 * (1.0 - R); }
+                    else { rr = s0 + 0.0; rg = s1 + 0.0; rb = s2 + 0.0; }
                 } else {
-                    // refracted child finished (world.rs:190-192)
-                    const double transp = m->transparency;
+                    // the only child was the refracted ray; reflected is black
+                    const double transp = f.transp;
                     rr = rr * transp; rg = rg * transp; rb = rb * transp;
-                }
-                // combine (world.rs:141-148)
-                if (f.flags & 4) {
-                    const double R = f.reflectance;
-                    rr = f.sr + f.ar * R + rr * (1.0 - R);
-                    rg = f.sg + f.ag * R + rg * (1.0 - R);
-                    rb = f.sb + f.ab * R + rb * (1.0 - R);
-                } else {
-                    rr = f.sr + f.ar + rr; rg = f.sg + f.ag + rg; rb = f.sb + f.ab + rb;
+                    if (fl & FR_BOTH) { rr = s0 + 0.0 * R + rr * (1.0 - R); rg = s1 + 0.0 * R + rg * (1.0 - R); rb = s2 + 0.0 * R + rb * (1.0 - R); }
+                    else { rr = s0 + 0.0 + rr; rg = s1 + 0.0 + rg; rb = s2 + 0.0 + rb; }
                 }
                 sp--;
             }
         }
-    }
 
-    // ---- Canvas::write_pixel + Color::to_rgb (canvas.rs:31-33, color.rs:40-48)
-    if (valid) {
-        const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : py;
-        const size_t idx = (size_t)row * cam.hsize + px;
-        rgb[idx * 3 + 0] = quantise(resr);
-        rgb[idx * 3 + 1] = quantise(resg);
-        rgb[idx * 3 + 2] = quantise(resb);
-        if (hit_out) hit_out[idx] = primary_id;
+        // the next ray goes to LDS slot 0, where the traversal and the next shade read it
+        if (newray) {
+            double* s = lds_rays + lane;
+            s[0] = nro.x; s[64] = nro.y; s[128] = nro.z; s[192] = nrd.x; s[256] = nrd.y; s[320] = nrd.z;
+        }
     }
 
 #ifdef RTX_TIMING
@@ -790,7 +822,7 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
                                              int count_events, hipStream_t stream) {
     const int blocks = rp->tiles_x * rp->n_bands_local;
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = (size_t)sc->n_levels * LDS_LEVEL_DOUBLES * sizeof(double);
+    const size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double);
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
     if (count_events) {

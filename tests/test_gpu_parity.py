@@ -26,18 +26,6 @@ def test_device_math_bits(ctx):
     assert np.array_equal(ctx.debug_math(0, a), np.sqrt(a))
     assert np.array_equal(ctx.debug_math(1, a, b), a / b)
     assert np.array_equal(ctx.debug_math(3, b), np.floor(b))
-    # shared-reciprocal division (csrc/rtx_math.h): same bits as the host's `/` on the fast path (middle
-    # exponents) and on the guarded fall-back (denormals, huge, zero, inf, nan operands)
-    sp = np.array([0.0, -0.0, 5e-324, 1e-310, 2.0 ** -301, 2.0 ** -300, 2.0 ** 300, 2.0 ** 301, 1e308, np.inf, -np.inf,
-                   np.nan, 1.0, -3.0, 1e-200, 1e200])
-    xa = np.concatenate([a, np.repeat(sp, len(sp)), 10.0 ** rng.uniform(-320, 308, 300000) * rng.choice([-1.0, 1.0], 300000)])
-    xb = np.concatenate([b, np.tile(sp, len(sp)), 10.0 ** rng.uniform(-320, 308, 300000) * rng.choice([-1.0, 1.0], 300000)])
-    with np.errstate(all="ignore"):
-        want = xa / xb
-    for op in (7, 8, 9):
-        got = ctx.debug_math(op, xa, xb)
-        assert np.array_equal(got, want, equal_nan=True), op
-        assert np.array_equal(np.signbit(got[want == 0]), np.signbit(want[want == 0])), op
     x = rng.uniform(0, 1, 200000); y = rng.uniform(1, 400, 200000)
     p = ctx.debug_math(2, x, y); q = np.power(x, y)
     ok = np.abs(p - q) <= 4 * np.spacing(np.maximum(np.abs(q), 1e-300))
