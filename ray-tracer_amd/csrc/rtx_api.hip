@@ -348,6 +348,8 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     std::memset(bodies.data(), 0, bodies.size() * sizeof(OpBody));
     std::vector<HitRec> hits(cc.ops.size() + 1);
     std::memset(hits.data(), 0, hits.size() * sizeof(HitRec));
+    for (auto& o : cc.ops)
+        if (o.kind == OPK_PLANE && !(o.flags & (OPF_LIST | OPF_DIV))) o.flags |= OPF_INLINE;
     for (size_t i = 0; i < cc.ops.size(); i++) {
         const OpRec& o = cc.ops[i];
         OpHead& h = heads[i]; OpBody& b = bodies[i];
@@ -355,7 +357,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         h.skip = o.skip; h.shape = o.shape;
         std::memcpy(h.cull, o.cull, sizeof h.cull);
         std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33; std::memcpy(b.bounds, o.bounds, sizeof b.bounds);
-        b.div = (o.flags & OPF_DIV) ? 1 : 0;
+        b.div = (o.flags & OPF_DIV) ? 1 : 0; b.kind = o.kind;
         if (o.kind <= OPK_CUBE) {
             const ShapeRec& sr = cc.shapes[o.shape];
             HitRec& hr = hits[i];
@@ -363,14 +365,14 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
             hr.ri = d->materials[sr.material].refractive_index; hr.type = sr.type;
         }
     }
-    // runs of consecutive shapes with the same level and list flag, at most 64 long (one candidate bit each)
+    // runs of consecutive shapes with the same level, list flag and inline flag, at most 64 long (one candidate bit each)
     for (size_t i = cc.ops.size(); i-- > 0;) {
         const OpRec& o = cc.ops[i];
         if (o.kind > OPK_CUBE) continue;
         int run = 1;
         if (i + 1 < cc.ops.size()) {
             const OpRec& nx = cc.ops[i + 1];
-            if (nx.kind <= OPK_CUBE && nx.level == o.level && ((nx.flags ^ o.flags) & OPF_LIST) == 0 && heads[i + 1].run < 64)
+            if (nx.kind <= OPK_CUBE && nx.level == o.level && ((nx.flags ^ o.flags) & (OPF_LIST | OPF_INLINE)) == 0 && heads[i + 1].run < 64)
                 run = heads[i + 1].run + 1;
         }
         heads[i].run = run;

@@ -21,7 +21,9 @@ enum {
 enum {
     OPF_LIST = 1,      // inside a CSG root: hits go to the per-lane list, not the running state
     OPF_DIV = 2,       // inverse's w33 != 1.0: keep the point division (nalgebra Projective3*Point3)
-    OPF_ROOT = 4       // CSG_BEGIN/CSG_END of a CSG root (a CSG with no CSG ancestor)
+    OPF_ROOT = 4,      // CSG_BEGIN/CSG_END of a CSG root (a CSG with no CSG ancestor)
+    OPF_INLINE = 8     // plane outside CSG without point division: never culled, every lane tests it, so the
+                       //   exact test runs wave-uniformly in the sweep; a run is all-INLINE or has none
 };
 
 // Each op is split into a 32-byte head (all a culled visit touches; the head of the NEXT op is
@@ -46,7 +48,7 @@ struct OpBody {
     double w33;        // inverse(3,3)
     double bounds[6];  // containers: local bounds {min xyz, max xyz}
     int32_t div;       // w33 != 1.0 (copy of OPF_DIV, so shading needs no head load)
-    int32_t pad0;
+    int32_t kind;      // copy of the head's kind, so the per-lane exact tests read one record
     double pad[4];
 };
 

@@ -290,21 +290,27 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
         const bool is_shadow = mode == MODE_SHADOW;
 
+        // The running state is ORDER-INDEPENDENT: ties in t resolve by op index (= the reference's visiting
+        // order, which its stable sorts preserve), so shapes of one run may be fed in any order.
+        // closest hit: smallest (t, op); innermost open containers: largest (t, op)
+        auto closer = [&](double t, int op) { return best_op < 0 || t < best_t || (t == best_t && op < best_op); };
+        auto later = [&](double t, int op, double ct, int cs) { return t > ct || (t == ct && op > cs); };
+        auto enter = [&](double t, int op) {
+            if (later(t, op, c1t, c1s)) { c2t = c1t; c2s = c1s; c1t = t; c1s = op; }
+            else if (later(t, op, c2t, c2s)) { c2t = t; c2s = op; }
+        };
         // feed the hits of one shape (sorted, k <= 2) into the running state
         auto feed = [&](int k, double t0, double t1, int shape) {
             if (k == 0) return;
             const bool nn0 = t0 >= 0.0;
             if (nn0) {
-                if (best_op < 0 || t0 < best_t) { best_t = t0; best_op = shape; best_inside = false; }
+                if (closer(t0, shape)) { best_t = t0; best_op = shape; best_inside = false; }
             } else {
                 if (k == 2 && t1 >= 0.0) {
-                    if (best_op < 0 || t1 < best_t) { best_t = t1; best_op = shape; best_inside = true; }
+                    if (closer(t1, shape)) { best_t = t1; best_op = shape; best_inside = true; }
                 }
                 // exactly one negative entry -> the shape is an open container behind the origin
-                if (k == 1 || t1 >= 0.0) {
-                    if (t0 >= c1t) { c2t = c1t; c2s = c1s; c1t = t0; c1s = shape; }
-                    else if (t0 >= c2t) { c2t = t0; c2s = shape; }
-                }
+                if (k == 1 || t1 >= 0.0) enter(t0, shape);
             }
         };
 
@@ -344,11 +350,32 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 TM(tm_other);
                 const int R = H_RUN(h);
                 sync_level(level);
-                // ---- phase 1: conservative bounding-sphere pre-test of every op of the run for every
-                // lane (cull_miss: no counterpart in the reference, cannot change a result).  Tight
-                // uniform loop: one scalar head load + ~16 f32 VALU per op, no per-lane state but `cand`.
                 uint64_t cand = 0;
-                {
+                bool live = active;           // lane still wants hits (a shadow ray may be decided mid-run)
+                if (flags & OPF_INLINE) {
+                    // ---- a run of planes (OPF_INLINE): a plane is never culled and every lane tests it, so the
+                    // exact test (plane.rs:16-23, only the y row of the local ray) runs here, wave-uniformly,
+                    // with the row arriving through scalar loads one op ahead
+                    typedef double Row __attribute__((ext_vector_type(4)));
+                    Row row = *(const AS4 Row*)&(bodies + cur)->inv[4];
+                    for (int i = 0; i < R; i++) {
+                        const Row rnext = *(const AS4 Row*)&(bodies + cur + i + 1)->inv[4];   // (array is padded)
+                        const double loy = row[0] * po.x + row[1] * po.y + row[2] * po.z + row[3];
+                        const double ldy = row[0] * pd.x + row[1] * pd.y + row[2] * pd.z;
+                        if (active) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_PLANE, 1); }
+                        if (live) {
+                            EV(RTX_EV_X_XFORM, 1);
+                            if (!(__builtin_fabs(ldy) < 1e-12)) {
+                                feed(1, -loy / ldy, 0.0, cur + i);
+                                if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; live = false; }
+                            }
+                        }
+                        row = rnext;
+                    }
+                } else {
+                    // ---- phase 1: conservative bounding-sphere pre-test of every op of the run for every
+                    // lane (cull_miss: no counterpart in the reference, cannot change a result).  Tight
+                    // uniform loop: one scalar head load + ~16 f32 VALU per op, no per-lane state but `cand`.
                     Head hh = h;
                     for (int i = 0; i < R; i++) {
                         const Head hnext = load_head(heads + cur + i + 1);     // prefetch (array is padded)
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         hh = hnext;
                     }
                 }
-                if (!active) cand = 0;
+                if (!live) cand = 0;
                 EV(RTX_EV_OP_SLOTS, R);
                 TM(tm_ffwd);
                 // ---- phase 2: every lane walks ITS OWN surviving ops in program order (lowest bit first,
@@ -376,7 +403,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         cand &= cand - 1;
                         const int idx = cur + i;
                         const OpBody* gb = sc.bodies + idx;
-                        const int k1 = OPH_KIND(sc.heads[idx].info);
+                        const int k1 = gb->kind;
                         V3 lo = xf_point(gb->inv, gb->w33, gb->div != 0, po);
                         V3 ld = xf_vector(gb->inv, pd);
                         EV(RTX_EV_X_XFORM, 1);
@@ -515,11 +542,10 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                                 for (int j = 0; j < cnt; j++)
                                     if ((int)(ls[j] & ~LBIT) == shape && !(lt[j] >= 0.0)) negs++;
                                 if (t >= 0.0) {
-                                    if (best_op < 0 || t < best_t) { best_t = t; best_op = shape; best_inside = (negs == 1); }
-                                    break;      // later entries are larger
+                                    if (closer(t, shape)) { best_t = t; best_op = shape; best_inside = (negs == 1); }
+                                    break;      // later entries are larger (or tie with a later op)
                                 } else if (negs == 1) {
-                                    if (t >= c1t) { c2t = c1t; c2s = c1s; c1t = t; c1s = shape; }
-                                    else if (t >= c2t) { c2t = t; c2s = shape; }
+                                    enter(t, shape);
                                 }
                             }
                             cnt = 0;
