@@ -49,7 +49,7 @@ struct rtx_scene {
     rtx_ctx* ctx = nullptr;
     SceneDev dev{};
     void* d_ops = nullptr; void* d_bodies = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
-    void* d_materials = nullptr; void* d_lights = nullptr;
+    void* d_materials = nullptr; void* d_lights = nullptr; void* d_pairs = nullptr;
 };
 
 namespace {
@@ -365,14 +365,15 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
             hr.ri = d->materials[sr.material].refractive_index; hr.type = sr.type;
         }
     }
-    // runs of consecutive shapes with the same level, list flag and inline flag, at most 64 long (one candidate bit each)
+    // runs of consecutive shapes with the same level, list flag and inline flag, at most 60 long (one candidate bit each, plus up
+    // to three for the quad partners of an unaligned first op)
     for (size_t i = cc.ops.size(); i-- > 0;) {
         const OpRec& o = cc.ops[i];
         if (o.kind > OPK_CUBE) continue;
         int run = 1;
         if (i + 1 < cc.ops.size()) {
             const OpRec& nx = cc.ops[i + 1];
-            if (nx.kind <= OPK_CUBE && nx.level == o.level && ((nx.flags ^ o.flags) & (OPF_LIST | OPF_INLINE)) == 0 && heads[i + 1].run < 64)
+            if (nx.kind <= OPK_CUBE && nx.level == o.level && ((nx.flags ^ o.flags) & (OPF_LIST | OPF_INLINE)) == 0 && heads[i + 1].run < 60)
                 run = heads[i + 1].run + 1;
         }
         heads[i].run = run;
@@ -382,13 +383,16 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         for (size_t i = 0; i < heads.size(); i++)
             fprintf(stderr, "head %zu: info=%08x skip=%d shape=%d cull=%g %g %g %g\n", i, heads[i].info, heads[i].skip,
                     heads[i].shape, heads[i].cull[0], heads[i].cull[1], heads[i].cull[2], heads[i].cull[3]);
-    if ((rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
+    std::vector<float> pairs(((heads.size() + 3) / 4 + 2) * 16, INFINITY);   // whole quads + two quads of padding
+    for (size_t i = 0; i < heads.size(); i++)
+        for (int k = 0; k < 4; k++) pairs[(i / 2) * 8 + k * 2 + (i & 1)] = heads[i].cull[k];
+    if ((rc = upload(ctx, pairs, &s->d_pairs)) || (rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
         (rc = upload(ctx, lights, &s->d_lights))) {
         rtx_scene_destroy(s);
         return rc;
     }
-    s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.hits = (const HitRec*)s->d_shapes;
+    s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.cull_pairs = (const float*)s->d_pairs; s->dev.hits = (const HitRec*)s->d_shapes;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
@@ -407,6 +411,7 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_paths) (void)hipFree(s->d_paths);
     if (s->d_materials) (void)hipFree(s->d_materials);
     if (s->d_lights) (void)hipFree(s->d_lights);
+    if (s->d_pairs) (void)hipFree(s->d_pairs);
     delete s;
 }
 

@@ -36,7 +36,7 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
     int32_t skip;      // BEGIN ops: index just past the matching END
     int32_t shape;     // CSG ops: operator (shape ops: ShapeIndex, informational; the kernel identifies a
                        //   shape by its OP INDEX and reads HitRec[op] when it shades)
-    int32_t run;       // shape ops: ops left in this run of consecutive same-level shapes (1..64), else 0
+    int32_t run;       // shape ops: ops left in this run of consecutive same-level shapes (1..60), else 0
     float cull[4];     // bounding sphere in PARENT space: centre xyz, radius^2 (inflated); +inf = never cull
 };
 #define OPH_KIND(i) ((int)((i) & 15u))
@@ -86,6 +86,8 @@ struct LightRec { double pos[3]; double intensity[3]; };
 struct SceneDev {
     const OpHead* heads;      // n_ops + 2 entries (padding so the 2-deep prefetch never runs off the end)
     const OpBody* bodies;
+    const float* cull_pairs;  // per PAIR of ops (2j, 2j+1): {cxA,cxB, cyA,cyB, czA,czB, r2A,r2B}, copy of the heads' spheres
+                              //   laid out for packed-f32 math (two ops per VALU instruction)
     const HitRec* hits;       // n_ops + 1 entries, valid at shape ops
     const int32_t* path_ops;
     const MaterialRec* materials;

@@ -187,6 +187,26 @@ DI V3 to_object(const SceneDev& sc, const HitRec& hr, int hop, V3 p) {
     return xf_point(xo->inv, xo->w33, xo->div != 0, p);
 }
 
+// the same pre-test for a PAIR of ops in packed f32 (v_pk_*_f32: two ops per instruction); p = {cxA,cxB,
+// cyA,cyB, czA,czB, r2A,r2B}.  Returns bit 0 / bit 1 = op A / op B may be hit (NaN counts as "may be hit").
+typedef float F2 __attribute__((ext_vector_type(2)));
+typedef float F8 __attribute__((ext_vector_type(8)));
+DI unsigned cull_hit2(F8 p, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd) {
+    const F2 ocx = F2{p[0], p[1]} - F2{fox, fox}, ocy = F2{p[2], p[3]} - F2{foy, foy}, ocz = F2{p[4], p[5]} - F2{foz, foz};
+    const F2 dx = {fdx, fdx}, dy = {fdy, fdy}, dz = {fdz, fdz}, dd = {fdd, fdd};
+    const F2 od = __builtin_elementwise_fma(ocz, dz, __builtin_elementwise_fma(ocy, dy, ocx * dx));
+    const F2 oo = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx));
+    const F2 lhs = __builtin_elementwise_fma(oo, dd, -(od * od));              // dist^2 * |d|^2
+    const F2 rhs = __builtin_elementwise_fma(F2{CULL_KAPPA, CULL_KAPPA}, oo, F2{p[6], p[7]}) * dd;
+    return (lhs[0] > rhs[0] ? 0u : 1u) | (lhs[1] > rhs[1] ? 0u : 2u);
+}
+typedef float F16 __attribute__((ext_vector_type(16)));
+DI unsigned cull_hit4(F16 p, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd) {
+    const F8 lo = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+    const F8 hi = {p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]};
+    return cull_hit2(lo, fox, foy, foz, fdx, fdy, fdz, fdd) | (cull_hit2(hi, fox, foy, foz, fdx, fdy, fdz, fdd) << 2);
+}
+
 enum { MODE_DONE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
 const uint32_t LBIT = 0x80000000u;
 
@@ -374,21 +394,37 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                     }
                 } else {
                     // ---- phase 1: conservative bounding-sphere pre-test of every op of the run for every
-                    // lane (cull_miss: no counterpart in the reference, cannot change a result).  Tight
-                    // uniform loop: one scalar head load + ~16 f32 VALU per op, no per-lane state but `cand`.
-                    Head hh = h;
-                    for (int i = 0; i < R; i++) {
-                        const Head hnext = load_head(heads + cur + i + 1);     // prefetch (array is padded)
-                        const bool miss = cull_miss(hh, fox, foy, foz, fdx, fdy, fdz, fdd);
-                        cand |= miss ? 0ull : (1ull << i);
-                        if (COUNT && active) {
-                            const int kk = OPH_KIND(H_INFO(hh));
-                            EV(RTX_EV_XFORM, 1); EV(RTX_EV_CULL, 1);
+                    // lane (cull_miss2: no counterpart in the reference, cannot change a result).  Tight
+                    // uniform loop over PAIRS of ops (2j, 2j+1): one scalar load of the pair's spheres and
+                    // ~15 packed-f32 VALU instructions per pair, no per-lane state but the candidate bits.
+                    // Scalar loads return out of order (only lgkmcnt(0) can be waited for), so the loop is a
+                    // ping-pong over QUADS of ops: one s_load_dwordx16 (two pairs) is in flight while the
+                    // previous quad is evaluated.  The pointers are made opaque so the rotation is not folded away.
+                    const AS4 F16* cq = (const AS4 F16*)(uintptr_t)sc.cull_pairs;
+                    const int q0 = cur >> 2, q1 = (cur + R - 1) >> 2;
+                    uint64_t acc = 0;
+                    F16 qa = cq[q0];
+                    for (int q = q0; q <= q1; q += 2) {
+                        const AS4 F16* pb = cq + q + 1;
+                        asm volatile("" : "+s"(pb));
+                        const F16 qb = *pb;                                      // (array is padded by two quads)
+                        acc |= (uint64_t)cull_hit4(qa, fox, foy, foz, fdx, fdy, fdz, fdd) << (4 * (q - q0));
+                        const AS4 F16* pa = cq + q + 2;
+                        asm volatile("" : "+s"(pa));
+                        qa = *pa;
+                        // (branch-free so both loads stay ahead of the math: past the end the bits are masked off)
+                        const unsigned keep = (q + 1 <= q1) ? 0xfu : 0u;
+                        acc |= (uint64_t)(cull_hit4(qb, fox, foy, foz, fdx, fdy, fdz, fdd) & keep) << ((4 * (q + 1 - q0)) & 63);
+                    }
+                    cand = (acc >> (cur & 3)) & ((1ull << R) - 1ull);            // (cur & 3) + R <= 64
+                    if (COUNT && active) {
+                        EV(RTX_EV_XFORM, R); EV(RTX_EV_CULL, R);
+                        for (int i = 0; i < R; i++) {
+                            const int kk = OPH_KIND(heads[cur + i].info);
                             if (kk == OPK_SPHERE) EV(RTX_EV_SPHERE, 1);
                             else if (kk == OPK_PLANE) EV(RTX_EV_PLANE, 1);
                             else EV(RTX_EV_CUBE, 1);
                         }
-                        hh = hnext;
                     }
                 }
                 if (!live) cand = 0;
