@@ -14,6 +14,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
+#include "rtx_pow.h"
 
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
@@ -30,6 +31,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 3: r = __builtin_floor(x); break;
         case 4: r = __builtin_round(x); break;
         case 5: r = __builtin_fmax(x, y); break;
+        case 7: r = rtx_spec_pow(x, y); break;
         default: r = __builtin_fmin(x, y); break;
     }
     out[i] = r;
@@ -416,7 +418,7 @@ void rtx_scene_destroy(rtx_scene* s) {
 }
 
 int rtx_debug_math(rtx_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out) {
-    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 6) return RTX_E_INVALID;
+    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 7) return RTX_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)n * sizeof(double);

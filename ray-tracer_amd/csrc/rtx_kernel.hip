@@ -28,6 +28,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
+#include "rtx_pow.h"
 
 #define DI __device__ __forceinline__
 #define AS4 __attribute__((address_space(4)))
@@ -250,6 +251,15 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
 #else
 #define TM(acc) do { } while (0)
 #endif
+    // RTX_TIMING == 2: the traversal is one bucket ("other") and the cull/exact slots time the shadow-ray
+    // set-up and the children decision instead; "shade" is then the unwind + loop turn-around
+#if defined(RTX_TIMING) && RTX_TIMING == 2
+#define TMT(acc) TM(tm_other)
+#define TMS(acc) TM(acc)
+#else
+#define TMT(acc) TM(acc)
+#define TMS(acc) do { } while (0)
+#endif
 
     int mode;
     // ---- Camera::ray_for_pixel (camera.rs:56-69); the ray goes to LDS slot 0
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 }
                 if (!live) cand = 0;
                 EV(RTX_EV_OP_SLOTS, R);
-                TM(tm_ffwd);
+                TMT(tm_ffwd);
                 // ---- phase 2: every lane walks ITS OWN surviving ops in program order (lowest bit first,
                 // so ties resolve as in the reference's stable sort); node records come through per-lane
                 // vector loads.  ObjectStore::intersect (object_store.rs:243-260) for one shape per lane.
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                     }
                 }
                 next = cur + R;
-                TM(tm_body);
+                TMT(tm_body);
             } else if (kind == OPK_GROUP_BEGIN || kind == OPK_CSG_BEGIN) {
                 sync_level(level);
                 if (active) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_BOUNDS, 1); }
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 const double rde = dot3(rv, eyev);
                 if (!(rde <= 0.0)) {
                     EV(RTX_EV_POW, 1);
-                    const double factor = pow(rde, m->shininess);
+                    const double factor = rtx_spec_pow(rde, m->shininess);
                     const double spec = m->specular;
                     spr = ir * spec * factor; spg = ig * spec * factor; spb = ib * spec * factor;
                 }
@@ -723,6 +733,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             newray = true;
             mode = MODE_SHADOW;
         }
+        TMS(tm_ffwd);
 
         if (lights_done) {
             // ---- rest of shade_hit (world.rs:138-148): decide the children
@@ -797,6 +808,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             }
         }
 
+        TMS(tm_body);
         // ---- unwind: hand finished colours to the waiting frames (post-order)
         while (returning) {
             if (sp == 0) {

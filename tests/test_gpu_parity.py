@@ -30,6 +30,14 @@ def test_device_math_bits(ctx):
     p = ctx.debug_math(2, x, y); q = np.power(x, y)
     ok = np.abs(p - q) <= 4 * np.spacing(np.maximum(np.abs(q), 1e-300))
     assert ok.all(), "pow differs from glibc by more than 4 ulp"
+    # specular power (csrc/rtx_pow.h): integer exponents by binary powering, relative error <= n * 2^-53 (+ margin);
+    # anything else is the library pow
+    yi = rng.integers(0, 400, 200000).astype(np.float64)
+    p = ctx.debug_math(7, x, yi); q = np.power(x, yi)
+    assert (np.abs(p - q) <= (yi + 4) * 2.0 ** -52 * np.abs(q) + 1e-320).all(), "integer power outside n * 2^-52"
+    p = ctx.debug_math(7, x, y); q = np.power(x, y)
+    assert (np.abs(p - q) <= 4 * np.spacing(np.maximum(np.abs(q), 1e-300))).all()
+    assert ctx.debug_math(7, np.array([0.5, 0.5, 2.0]), np.array([0.0, 1.0, 4096.0])).tolist() == [1.0, 0.5, np.inf]
     nan = float("nan")
     assert ctx.debug_math(5, np.array([nan, 1.0, nan]), np.array([2.0, nan, nan]))[:2].tolist() == [2.0, 1.0]
 
