@@ -102,6 +102,7 @@ enum {
     RTX_EV_X_XFORM,      /* exact ray-into-node transforms executed */
     RTX_EV_X_SPHERE,     /* exact sphere tests executed */
     RTX_EV_X_BOX,        /* exact cube / bounds slab tests executed */
+    RTX_EV_BACKFACE,     /* light evaluations with light_dot_normal < 0 (the shadow answer cannot matter) */
     RTX_EV_USED,
     RTX_EV_COUNT = 24
 };

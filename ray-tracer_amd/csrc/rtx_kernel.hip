@@ -701,6 +701,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
             double cr = er * amb, cg = eg * amb, cb = eb * amb;                   // ambient
             double dr = 0.0, dg = 0.0, db = 0.0, spr = 0.0, spg = 0.0, spb = 0.0;
             const double ldn = dot3(lightv, nv);
+            if (ldn < 0.0) EV(RTX_EV_BACKFACE, 1);
             if (!(in_shadow || ldn < 0.0)) {
                 const double dif = m->diffuse;
                 dr = er * dif * ldn; dg = eg * dif * ldn; db = eb * dif * ldn;

@@ -22,7 +22,7 @@ D6 = C.c_double * 6
 D16 = C.c_double * 16
 EV_COUNT = 16          # event slots of the host-API stats struct (the device stats in rtx.py hold 24)
 EV_NAMES = ["xform", "sphere", "plane", "cube", "bounds", "csg_entries", "hit", "levels",
-            "light", "pow", "refr", "schlick", "lane_slots", "op_slots", "cull", "x_xform", "x_sphere", "x_box"]
+            "light", "pow", "refr", "schlick", "lane_slots", "op_slots", "cull", "x_xform", "x_sphere", "x_box", "backface"]
 
 
 REF_EVENTS = EV_NAMES[:12]          # reference-defined events (the oracle counts exactly these)
