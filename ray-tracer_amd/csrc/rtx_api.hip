@@ -32,6 +32,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 4: r = __builtin_round(x); break;
         case 5: r = __builtin_fmax(x, y); break;
         case 7: r = rtx_spec_pow(x, y); break;
+        case 8: r = __builtin_amdgcn_rcp(x); break;                           // raw v_rcp_f64 (accuracy probe for the slab filter)
         default: r = __builtin_fmin(x, y); break;
     }
     out[i] = r;
@@ -356,6 +357,11 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         const OpRec& o = cc.ops[i];
         OpHead& h = heads[i]; OpBody& b = bodies[i];
         h.info = (uint32_t)o.kind | ((uint32_t)o.flags << 4) | ((uint32_t)o.level << 8) | ((uint32_t)o.clevel << 16);
+        if (o.kind == OPK_GROUP_BEGIN || o.kind == OPK_CSG_BEGIN) {
+            bool ok = true;
+            for (int k = 0; k < 6; k++) ok = ok && (std::isinf(o.bounds[k]) || std::fabs(o.bounds[k]) <= 1e100);   // NaN fails both
+            if (!ok) h.info |= 1u << 24;
+        }
         h.skip = o.skip; h.shape = o.shape;
         std::memcpy(h.cull, o.cull, sizeof h.cull);
         std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33; std::memcpy(b.bounds, o.bounds, sizeof b.bounds);
@@ -418,7 +424,7 @@ void rtx_scene_destroy(rtx_scene* s) {
 }
 
 int rtx_debug_math(rtx_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out) {
-    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 7) return RTX_E_INVALID;
+    if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 8) return RTX_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)n * sizeof(double);

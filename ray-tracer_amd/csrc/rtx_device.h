@@ -30,7 +30,7 @@ enum {
 // prefetched while the current one is processed) and a 192-byte body (exact test only).  Both are
 // read through scalar loads (wave-uniform index).
 struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
-    uint32_t info;     // kind | flags << 4 | level << 8 | clevel << 16
+    uint32_t info;     // kind | flags << 4 | level << 8 | clevel << 16 | nofilter << 24
                        //   kind: OPK_*; flags: OPF_*; level: nesting depth (the ray to transform is the
                        //   local ray of level-1, 0 = world ray); clevel: container level inside a CSG root
     int32_t skip;      // BEGIN ops: index just past the matching END
@@ -43,6 +43,7 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
 #define OPH_FLAGS(i) ((int)(((i) >> 4) & 15u))
 #define OPH_LEVEL(i) ((int)(((i) >> 8) & 255u))
 #define OPH_CLEVEL(i) ((int)(((i) >> 16) & 255u))
+#define OPH_NOFILTER(i) ((int)(((i) >> 24) & 1u))   // container bounds unsuitable for the interval filter (NaN or |finite| > 1e100)
 struct OpBody {
     double inv[12];    // rows 0..2 of inverse(transform): inv[r*4+c]
     double w33;        // inverse(3,3)
