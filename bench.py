@@ -88,16 +88,38 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (e.g. 2 ranks, gloo, one GPU):
+    # RTX_BENCH_BACKEND=gloo maps every rank onto the GPUs that exist.  The driver's runs never set it.
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     N = args.gpus
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
         N = world_size
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace-and-shade path has no CPU fallback")
+
+    # collectives: RCCL on device tensors; the gloo rehearsal stages through host memory
+    def all_reduce(t, op=None):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+        else:
+            c = t.cpu(); dist.all_reduce(c, op=op or dist.ReduceOp.SUM); t.copy_(c)
+
+    def all_gather(out, inp):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out, inp)
+        else:
+            parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(world_size)]
+            dist.all_gather(parts, inp.cpu()); out.copy_(torch.cat(parts))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -120,7 +142,7 @@ def main():
     def step(stats=False):
         st = scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, stats)
         if N > 1:
-            dist.all_gather_into_tensor(gathered, local)
+            all_gather(gathered, local)
         return st
 
     # exact ray and event counts of this rank's share (untimed)
@@ -132,7 +154,7 @@ def main():
     counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_secondary, fl_local, fl_exec,
                            evs["cull"], evs["x_xform"], evs["xform"]], dtype=torch.float64, device=dev)
     if N > 1:
-        dist.all_reduce(counts)
+        all_reduce(counts)
     rays_frame = int(counts[0] + counts[1] + counts[2])
 
     for _ in range(args.warmup):
@@ -147,7 +169,7 @@ def main():
         scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
         ev[k][1].record()
         if N > 1:
-            dist.all_gather_into_tensor(gathered, local)
+            all_gather(gathered, local)
     torch.cuda.synchronize()
     if N > 1:
         dist.barrier()
@@ -155,13 +177,14 @@ def main():
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / args.steps], dtype=torch.float64, device=dev)
     if N > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
+        all_reduce(elapsed, dist.ReduceOp.MAX)
+        all_reduce(kern_ms, dist.ReduceOp.MAX)
     elapsed = float(elapsed[0]); kern_ms = float(kern_ms[0])
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1000.0
-        achieved = float(counts[3]) / (kern_ms / 1000.0) / 1e12
+        # per launch (= per GPU): each rank's launch does 1/N of the frame's flops in kern_ms (slowest rank)
+        achieved = float(counts[3]) / N / (kern_ms / 1000.0) / 1e12
         out = {
             "metric": "Mrays/sec (primary+shadow+secondary)", "value": rays_frame * args.steps / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
