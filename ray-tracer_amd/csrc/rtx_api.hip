@@ -5,6 +5,7 @@
 // cannot provide a device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,7 @@ struct rtx_scene {
     SceneDev dev{};
     void* d_ops = nullptr; void* d_bodies = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
     void* d_materials = nullptr; void* d_lights = nullptr; void* d_pairs = nullptr;
+    void* d_chunks = nullptr; void* d_counts = nullptr; void* d_lcull = nullptr; void* d_lops = nullptr; void* d_conts = nullptr;
 };
 
 namespace {
@@ -246,6 +248,83 @@ struct Compiler {
     }
 };
 
+// Child lists for the list-by-list traversal outside CSG (rtx_device.h: ListChunk / ContRec)
+struct ListBuilder {
+    const std::vector<OpRec>& ops;
+    std::vector<ListChunk> chunks;
+    std::vector<ChunkCounts> counts;
+    std::vector<float> cull;          // 4 floats per child slot, pair-interleaved per quad
+    std::vector<int32_t> lops;
+    std::vector<ContRec> conts;
+    explicit ListBuilder(const std::vector<OpRec>& o) : ops(o) {}
+
+    void put_cull(size_t slot, const float* c4) {
+        const size_t q = slot / 4, p = slot % 4;
+        if (cull.size() < (q + 1) * 16) cull.resize((q + 1) * 16, INFINITY);
+        for (int k = 0; k < 4; k++) cull[q * 16 + (p / 2) * 8 + k * 2 + (p & 1)] = c4[k];
+    }
+    // children of the op range [begin, end); returns the index of the list's first chunk
+    int build(int begin, int end) {
+        std::vector<int> kids;
+        for (int i = begin; i < end;) {
+            kids.push_back(i);
+            const int k = ops[i].kind;
+            i = (k == OPK_GROUP_BEGIN || k == OPK_CSG_BEGIN) ? ops[i].skip : i + 1;
+        }
+        const int nchunks = kids.empty() ? 1 : (int)((kids.size() + 31) / 32);
+        const int first = (int)chunks.size();
+        chunks.resize(first + nchunks); counts.resize(first + nchunks);
+        std::vector<std::pair<int, int>> groups;      // (cont_recs index, op) to recurse into afterwards
+        for (int c = 0; c < nchunks; c++) {
+            ListChunk ch; std::memset(&ch, 0, sizeof ch);
+            ChunkCounts cn; std::memset(&cn, 0, sizeof cn);
+            const int k0 = c * 32, n = std::min<int>(32, (int)kids.size() - k0);
+            ch.n = n < 0 ? 0 : n;
+            while (lops.size() % 4) lops.push_back(-1);
+            ch.child_base = (int)lops.size();
+            ch.next = c + 1 < nchunks ? first + c + 1 : -1;
+            ch.cont_base = (int)conts.size();
+            bool consec = ch.n > 0;
+            for (int k = 0; k < ch.n; k++) {
+                const int op = kids[k0 + k];
+                const OpRec& o = ops[op];
+                if (op != kids[k0] + k) consec = false;
+                lops.push_back(op);
+                put_cull((size_t)ch.child_base + k, o.cull);
+                if (o.kind == OPK_GROUP_BEGIN || o.kind == OPK_CSG_BEGIN) {
+                    ch.cont_mask |= 1u << k; cn.containers++;
+                    ContRec r; std::memset(&r, 0, sizeof r);
+                    std::memcpy(r.inv, o.inv, sizeof r.inv); r.w33 = o.w33; std::memcpy(r.bounds, o.bounds, sizeof r.bounds);
+                    std::memcpy(r.cull, o.cull, sizeof r.cull);
+                    r.op = op; r.skip = o.skip; r.list = -1;
+                    bool ok = true;
+                    for (int b = 0; b < 6; b++) ok = ok && (std::isinf(o.bounds[b]) || std::fabs(o.bounds[b]) <= 1e100);
+                    r.flags = ((o.flags & OPF_DIV) ? CONT_DIV : 0) | (ok ? 0 : CONT_NOFILTER) | (o.kind == OPK_CSG_BEGIN ? CONT_CSG : 0);
+                    if (o.kind == OPK_GROUP_BEGIN) groups.push_back({(int)conts.size(), op});
+                    conts.push_back(r);
+                } else if (o.flags & OPF_INLINE) {
+                    ch.plane_mask |= 1u << k; cn.planes++;
+                } else {
+                    ch.shape_mask |= 1u << k;
+                    if (o.kind == OPK_SPHERE) cn.spheres++; else if (o.kind == OPK_PLANE) cn.planes++; else cn.cubes++;
+                }
+            }
+            ch.op0 = consec ? kids[k0] : -1;
+            chunks[first + c] = ch; counts[first + c] = cn;
+        }
+        for (auto& g : groups) {
+            const int li = build(g.second + 1, ops[g.second].skip);     // (no END op is emitted outside CSG)
+            conts[g.first].list = li;
+        }
+        return first;
+    }
+    void finish() {
+        while (lops.size() % 4) lops.push_back(-1);
+        cull.resize((lops.size() / 4 + 3) * 16, INFINITY);              // whole quads + padding for the look-ahead loads
+        if (conts.empty()) { ContRec r; std::memset(&r, 0, sizeof r); conts.push_back(r); }
+    }
+};
+
 template <typename T>
 int upload(rtx_ctx* ctx, const std::vector<T>& v, void** out) {
     *out = nullptr;
@@ -394,13 +473,20 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     std::vector<float> pairs(((heads.size() + 3) / 4 + 2) * 16, INFINITY);   // whole quads + two quads of padding
     for (size_t i = 0; i < heads.size(); i++)
         for (int k = 0; k < 4; k++) pairs[(i / 2) * 8 + k * 2 + (i & 1)] = heads[i].cull[k];
-    if ((rc = upload(ctx, pairs, &s->d_pairs)) || (rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
+    ListBuilder lb(cc.ops);
+    lb.build(0, (int)cc.ops.size());
+    lb.finish();
+    if ((rc = upload(ctx, lb.chunks, &s->d_chunks)) || (rc = upload(ctx, lb.counts, &s->d_counts)) || (rc = upload(ctx, lb.cull, &s->d_lcull)) ||
+        (rc = upload(ctx, lb.lops, &s->d_lops)) || (rc = upload(ctx, lb.conts, &s->d_conts)) ||
+        (rc = upload(ctx, pairs, &s->d_pairs)) || (rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
         (rc = upload(ctx, lights, &s->d_lights))) {
         rtx_scene_destroy(s);
         return rc;
     }
     s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.cull_pairs = (const float*)s->d_pairs; s->dev.hits = (const HitRec*)s->d_shapes;
+    s->dev.chunks = (const ListChunk*)s->d_chunks; s->dev.chunk_counts = (const ChunkCounts*)s->d_counts; s->dev.list_cull = (const float*)s->d_lcull;
+    s->dev.list_ops = (const int32_t*)s->d_lops; s->dev.cont_recs = (const ContRec*)s->d_conts;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
@@ -420,6 +506,7 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_materials) (void)hipFree(s->d_materials);
     if (s->d_lights) (void)hipFree(s->d_lights);
     if (s->d_pairs) (void)hipFree(s->d_pairs);
+    for (void* p : {s->d_chunks, s->d_counts, s->d_lcull, s->d_lops, s->d_conts}) if (p) (void)hipFree(p);
     delete s;
 }
 

@@ -53,6 +53,34 @@ struct OpBody {
     double pad[4];
 };
 
+// ---- child lists: the traversal outside CSG walks the graph list by list, not op by op.
+// A LIST is the ordered children of the world or of a group, cut into chunks of <= 32 children.  One sweep
+// (packed f32 bounding-sphere pre-test over the chunk's quads) tells every lane which children it may hit;
+// shapes are then tested per lane, and only the containers that SOME lane may hit are visited at all.
+struct ListChunk {           // 32 bytes = one s_load_dwordx8
+    int32_t n;               // children in this chunk (1..32)
+    int32_t child_base;      // multiple of 4: list_ops[child_base + k], spheres at list_cull[child_base * 4 ...]
+    uint32_t shape_mask;     // children with a per-lane exact test (spheres, cubes, planes with point division)
+    uint32_t plane_mask;     // OPF_INLINE planes: wave-uniform exact test
+    uint32_t cont_mask;      // groups and CSG roots
+    int32_t next;            // next chunk of the same list, or -1
+    int32_t op0;             // >= 0: child k is op (op0 + k), no list_ops lookup needed
+    int32_t cont_base;       // cont_recs[cont_base + r] = r-th container child of this chunk
+};
+#define LIST_KINDS_SHIFT 0
+struct ContRec {             // 192 bytes: everything a visit of a container child needs, one scalar round trip
+    double inv[12];          // rows 0..2 of inverse(transform)
+    double w33;
+    double bounds[6];
+    float cull[4];           // bounding sphere in parent space (same as the sweep's)
+    int32_t op;              // the container's BEGIN op
+    int32_t skip;            // op index past the container (range of a CSG root for the op interpreter)
+    int32_t list;            // first chunk of its child list (groups), -1 for a CSG root
+    int32_t flags;           // CONT_*
+};
+enum { CONT_DIV = 1, CONT_NOFILTER = 2, CONT_CSG = 4 };
+struct ChunkCounts { int32_t spheres, planes, cubes, containers; };   // per chunk, for the event counters
+
 // per ShapeIndex (host side only, while compiling)
 struct ShapeRec {
     int32_t type;        // OPK_SPHERE/PLANE/CUBE
@@ -87,6 +115,11 @@ struct LightRec { double pos[3]; double intensity[3]; };
 struct SceneDev {
     const OpHead* heads;      // n_ops + 2 entries (padding so the 2-deep prefetch never runs off the end)
     const OpBody* bodies;
+    const ListChunk* chunks;  // chunk 0 = first chunk of the world's list
+    const ChunkCounts* chunk_counts;
+    const float* list_cull;   // quads of bounding spheres in list order: {cxA,cxB,cyA,cyB,czA,czB,r2A,r2B} x 2 per 4 children
+    const int32_t* list_ops;  // op index per child slot
+    const ContRec* cont_recs;
     const float* cull_pairs;  // per PAIR of ops (2j, 2j+1): {cxA,cxB, cyA,cyB, czA,czB, r2A,r2B}, copy of the heads' spheres
                               //   laid out for packed-f32 math (two ops per VALU instruction)
     const HitRec* hits;       // n_ops + 1 entries, valid at shape ops

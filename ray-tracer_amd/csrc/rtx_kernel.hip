@@ -344,7 +344,9 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         // running state instead of a sorted hit list; shapes are identified by op index
         double best_t = 0.0; int best_op = -1; bool best_inside = false;
         double c1t = -INF, c2t = -INF; int c1s = -1, c2s = -1;     // refractive containers
-        int resume_at = (mode != MODE_DONE) ? 0 : n_ops;
+        int resume_at = n_ops;            // op interpreter (CSG roots): first op the lane takes part in again
+        int alive = (mode != MODE_DONE) ? 0 : -1;   // deepest list level the lane takes part in
+        bool decided = false;             // shadow ray already answered (world.rs:203-206)
         int cnt = 0;                      // CSG list length
         uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
         const bool is_shadow = mode == MODE_SHADOW;
@@ -389,8 +391,11 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         };
         sync_level(0);
 
-        int cur = 0;
-        while (cur < n_ops) {
+        // ---- the op interpreter: walks the ops [cur, end) of ONE CSG root in program order (hit lists need
+        // the reference's order); everything outside CSG goes through the child lists below
+        auto interpret = [&](int cur, const int end) {
+        const int root_op = cur;
+        while (cur < end) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             cached_level = __builtin_amdgcn_readfirstlane(cached_level);
             const bool active = cur >= resume_at;
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                             EV(RTX_EV_X_XFORM, 1);
                             if (!(__builtin_fabs(ldy) < 1e-12)) {
                                 feed(1, -loy / ldy, 0.0, cur + i);
-                                if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; live = false; }
+                                if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; live = false; decided = true; }
                             }
                         }
                         row = rnext;
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         } else {
                             feed(k, t0, t1, idx);
                             // is_shadowed (world.rs:203-206): any 0 <= t < distance decides
-                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; cand = 0; }
+                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; cand = 0; decided = true; }
                         }
                     }
                 }
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 TMT(tm_body);
             } else if (kind == OPK_GROUP_BEGIN || kind == OPK_CSG_BEGIN) {
                 sync_level(level);
-                if (active) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_BOUNDS, 1); }
+                if (active && cur != root_op) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_BOUNDS, 1); }   // (the root was counted with its list)
                 EV(RTX_EV_OP_SLOTS, 1);
                 // conservative pre-test of the container's bounding sphere (see cull_miss)
                 bool test = active;
@@ -632,12 +637,211 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                                 }
                             }
                             cnt = 0;
-                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) resume_at = n_ops;
+                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; decided = true; }
                         }
                     }
                 }
             }
             cur = next;
+        }
+        };
+
+        // ================= list-by-list traversal (everything outside CSG)
+        // Wave-uniform walk over child lists (rtx_device.h: ListChunk).  Per chunk: one packed-f32 sweep over
+        // the children's bounding spheres -> per-lane candidate bits; shapes are tested per lane; of the
+        // containers only those that SOME lane may hit are visited (one scalar round trip each: ContRec).
+        // A lane takes part in the list at `level` iff alive >= level (a lane that fails a group's test,
+        // group.rs:67, keeps alive at the parent's level).  The per-level (chunk, remaining containers) pairs
+        // live in two VGPRs used as lane-indexed uniform arrays.
+        {
+            const AS4 ListChunk* chunks = (const AS4 ListChunk*)(uintptr_t)sc.chunks;
+            const AS4 ContRec* conts = (const AS4 ContRec*)(uintptr_t)sc.cont_recs;
+            const AS4 F16* lq = (const AS4 F16*)(uintptr_t)sc.list_cull;
+            const AS4 int32_t* lops = (const AS4 int32_t*)(uintptr_t)sc.list_ops;
+            int level = 0, chunk = 0;
+            unsigned U = 0;
+            bool fresh = true;
+            int stk_chunk = 0, stk_U = 0;
+            Head hdr = load_head((const AS4 OpHead*)chunks);       // ListChunk has the size of a head: 8 dwords
+            for (;;) {
+                level = __builtin_amdgcn_readfirstlane(level);
+                chunk = __builtin_amdgcn_readfirstlane(chunk);
+                U = __builtin_amdgcn_readfirstlane(U);
+                cached_level = __builtin_amdgcn_readfirstlane(cached_level);
+                const bool act = alive >= level && !decided;
+                if (fresh) {
+                    fresh = false;
+                    U = 0;
+                    hdr = load_head((const AS4 OpHead*)(chunks + chunk));
+                    if (__any(act)) {
+                        TM(tm_other);
+                        const int n = (int)hdr[0], child_base = (int)hdr[1], op0 = (int)hdr[6];
+                        const unsigned shape_mask = hdr[2], plane_mask = hdr[3], cont_mask = hdr[4];
+                        sync_level(level);
+                        EV(RTX_EV_OP_SLOTS, n);
+                        if (COUNT && act) {
+                            const ChunkCounts cn = sc.chunk_counts[chunk];
+                            EV(RTX_EV_XFORM, cn.spheres + cn.planes + cn.cubes + cn.containers);
+                            EV(RTX_EV_SPHERE, cn.spheres); EV(RTX_EV_PLANE, cn.planes); EV(RTX_EV_CUBE, cn.cubes);
+                            EV(RTX_EV_BOUNDS, cn.containers); EV(RTX_EV_CULL, n);
+                        }
+                        // ---- sweep: conservative bounding-sphere pre-test of every child (cull_hit4: no counterpart
+                        // in the reference, cannot change a result).  Scalar loads return out of order (only
+                        // lgkmcnt(0) can be waited for), so the loop is a ping-pong over QUADS of children: two
+                        // s_load_dwordx16 are in flight per wait.  The pointers are opaque so the rotation stays.
+                        unsigned cand = 0;
+                        {
+                            const int q0 = child_base >> 2, nq = (n + 3) >> 2;
+                            unsigned acc = 0;
+                            F16 qa = lq[q0];
+                            for (int q = 0; q < nq; q += 2) {
+                                const AS4 F16* pb = lq + q0 + q + 1;
+                                asm volatile("" : "+s"(pb));
+                                const F16 qb = *pb;                              // (array is padded)
+                                acc |= cull_hit4(qa, fox, foy, foz, fdx, fdy, fdz, fdd) << (4 * q);
+                                const AS4 F16* pa = lq + q0 + q + 2;
+                                asm volatile("" : "+s"(pa));
+                                qa = *pa;
+                                // (branch-free so both loads stay ahead of the math: past the end the bits are masked off)
+                                acc |= cull_hit4(qb, fox, foy, foz, fdx, fdy, fdz, fdd) << ((4 * (q + 1)) & 31);
+                            }
+                            cand = acc & (n >= 32 ? ~0u : ((1u << n) - 1u));
+                        }
+                        if (!act) cand = 0;
+                        TMT(tm_ffwd);
+                        // ---- planes (OPF_INLINE): never culled, every lane tests them -> the exact test (plane.rs:16-23,
+                        // only the y row of the local ray) runs wave-uniformly with the row in SGPRs
+                        for (unsigned pm = plane_mask; pm != 0; pm &= pm - 1) {
+                            const int k = __builtin_ctz(pm);
+                            const int op = op0 >= 0 ? op0 + k : lops[child_base + k];
+                            typedef double Row __attribute__((ext_vector_type(4)));
+                            const Row row = *(const AS4 Row*)&(bodies + op)->inv[4];
+                            const double loy = row[0] * po.x + row[1] * po.y + row[2] * po.z + row[3];
+                            const double ldy = row[0] * pd.x + row[1] * pd.y + row[2] * pd.z;
+                            if (alive >= level && !decided) {
+                                EV(RTX_EV_X_XFORM, 1);
+                                if (!(__builtin_fabs(ldy) < 1e-12)) {
+                                    feed(1, -loy / ldy, 0.0, op);
+                                    if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) decided = true;
+                                }
+                            }
+                        }
+                        // ---- shapes: every lane walks ITS OWN surviving children; node records come through per-lane
+                        // vector loads.  ObjectStore::intersect (object_store.rs:243-260) for one shape per lane.
+                        unsigned sc_cand = decided ? 0u : (cand & shape_mask);
+                        while (__any(sc_cand != 0)) {
+                            if (sc_cand != 0) {
+                                const int i = __builtin_ctz(sc_cand);
+                                sc_cand &= sc_cand - 1;
+                                const int idx = op0 >= 0 ? op0 + i : sc.list_ops[child_base + i];
+                                const OpBody* gb = sc.bodies + idx;
+                                const int k1 = gb->kind;
+                                V3 lo = xf_point(gb->inv, gb->w33, gb->div != 0, po);
+                                V3 ld = xf_vector(gb->inv, pd);
+                                EV(RTX_EV_X_XFORM, 1);
+                                int k = 0; double t0 = 0.0, t1 = 0.0;
+                                if (k1 == OPK_SPHERE) {                   // sphere.rs:16-32
+                                    EV(RTX_EV_X_SPHERE, 1);
+                                    double a = dot3(ld, ld);
+                                    double b = 2.0 * dot3(ld, lo);
+                                    double c = dot3(lo, lo) - 1.0;
+                                    double disc = b * b - 4.0 * a * c;
+                                    if (!(disc < 0.0)) {
+                                        double sq = __builtin_sqrt(disc);
+                                        t0 = (-b - sq) / (2.0 * a);
+                                        t1 = (-b + sq) / (2.0 * a);
+                                        k = 2;
+                                    }
+                                } else if (k1 == OPK_PLANE) {             // plane.rs:16-23
+                                    if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
+                                } else {                                  // cube.rs:18-31
+                                    EV(RTX_EV_X_BOX, 1);
+                                    if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
+                                }
+                                feed(k, t0, t1, idx);
+                                // is_shadowed (world.rs:203-206): any 0 <= t < distance decides
+                                if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { decided = true; sc_cand = 0; }
+                            }
+                        }
+                        TMT(tm_body);
+                        // ---- containers that some lane may hit
+                        const unsigned cc = decided ? 0u : (cand & cont_mask);
+                        for (unsigned cm = cont_mask; cm != 0; cm &= cm - 1) {
+                            const unsigned bit = cm & (0u - cm);
+                            if (__any((cc & bit) != 0)) U |= bit;
+                        }
+                    }
+                }
+                if (U != 0) {
+                    const int c = __builtin_ctz(U);
+                    U &= U - 1;
+                    const AS4 ContRec* cr = conts + (int)hdr[7] + __builtin_popcount(hdr[4] & ((1u << c) - 1u));
+                    const int cflags = cr->flags;
+                    if (CSG && (cflags & CONT_CSG)) {
+                        if constexpr (CSG) {
+                            const int cop = cr->op, cend = cr->skip;
+                            resume_at = act ? cop : n_ops;
+                            cnt = 0; starts = 0; mids = 0;
+                            interpret(cop, cend);
+                        }
+                        continue;
+                    }
+                    // ---- Groups::local_intersect (group.rs:64-75): pre-test, ray into the group's space, bounds
+                    sync_level(level);
+                    EV(RTX_EV_OP_SLOTS, 1);
+                    bool test = act;
+                    {
+                        Head ch = {};
+                        ch[4] = __builtin_bit_cast(uint32_t, cr->cull[0]); ch[5] = __builtin_bit_cast(uint32_t, cr->cull[1]);
+                        ch[6] = __builtin_bit_cast(uint32_t, cr->cull[2]); ch[7] = __builtin_bit_cast(uint32_t, cr->cull[3]);
+                        if (cull_miss(ch, fox, foy, foz, fdx, fdy, fdz, fdd)) test = false;
+                    }
+                    if (__any(test)) {
+                        V3 lo = xf_point(cr->inv, cr->w33, (cflags & CONT_DIV) != 0, po);
+                        V3 ld = xf_vector(cr->inv, pd);
+                        if (test) EV(RTX_EV_X_XFORM, 1);
+                        // decision by the interval filter; the exact slab test (six divisions) only where a lane is undecided
+                        const int fdec = (cflags & CONT_NOFILTER) ? -1
+                            : slab_filter(lo, ld, cr->bounds[0], cr->bounds[1], cr->bounds[2], cr->bounds[3], cr->bounds[4], cr->bounds[5]);
+                        bool pass = test && fdec == 1;
+                        const bool undecided = test && fdec < 0;
+                        if (__any(undecided)) {
+                            if (undecided) EV(RTX_EV_X_BOX, 1);
+                            double tmin, tmax;
+                            const bool ex = slabs(lo, ld, cr->bounds[0], cr->bounds[1], cr->bounds[2],
+                                                  cr->bounds[3], cr->bounds[4], cr->bounds[5], tmin, tmax);
+                            pass = pass || (undecided && ex);
+                        }
+                        if (__any(pass)) {
+                            // the children (level + 1) walk in this group's space
+                            po = lo; pd = ld;
+                            fox = (float)lo.x; foy = (float)lo.y; foz = (float)lo.z;
+                            fdx = (float)ld.x; fdy = (float)ld.y; fdz = (float)ld.z;
+                            fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+                            cached_level = level + 1;
+                            if (pass) {
+                                double* s = lds_rays + (level + 1) * LDS_SLOT_DOUBLES + lane;
+                                s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
+                                s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
+                                alive = level + 1;
+                            }
+                            if (lane == level) { stk_chunk = chunk; stk_U = (int)U; }      // lane-indexed uniform arrays
+                            level = level + 1;
+                            chunk = cr->list;
+                            fresh = true;
+                        }
+                    }
+                    continue;
+                }
+                // this chunk is done: next chunk of the list, or back to the parent list
+                if ((int)hdr[5] >= 0) { chunk = (int)hdr[5]; fresh = true; continue; }
+                if (level == 0) break;
+                if (alive == level) alive = level - 1;
+                level = level - 1;
+                chunk = __builtin_amdgcn_readlane(stk_chunk, level);
+                U = (unsigned)__builtin_amdgcn_readlane(stk_U, level);
+                hdr = load_head((const AS4 OpHead*)(chunks + chunk));
+            }
         }
 
         TM(tm_other);
