@@ -147,6 +147,7 @@ struct Compiler {
     std::vector<char> seen;
     int max_container_level = -1;
     bool has_csg = false;
+    int max_csg_entries = 0;
     int err = RTX_OK;
     std::string msg;
 
@@ -241,6 +242,7 @@ struct Compiler {
             stack.pop_back();
             OpRec oe = make(-1, OPK_CSG_END, level, f, cl); oe.shape = cop; ops.push_back(oe);
             ops[b].skip = (int)ops.size();
+            if (root && entries > max_csg_entries) max_csg_entries = entries;
             if (root && entries > RTX_MAX_CSG_ENTRIES)
                 bad(RTX_E_CAPACITY, "CSG root can produce " + std::to_string(entries) + " hits > RTX_MAX_CSG_ENTRIES");
         }
@@ -491,7 +493,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     s->dev.lights = (const LightRec*)s->d_lights;
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
     s->dev.n_levels = cc.max_container_level + 2;   // slot 0 = world ray, slot L + 1 = local ray of the level-L container
-    s->dev.has_csg = cc.has_csg ? 1 : 0; s->dev.has_transparency = transp ? 1 : 0;
+    s->dev.csg_entries = cc.max_csg_entries; s->dev.has_csg = cc.has_csg ? 1 : 0; s->dev.has_transparency = transp ? 1 : 0;
     *out = s;
     return RTX_OK;
 }

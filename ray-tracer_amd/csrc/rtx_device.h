@@ -128,6 +128,7 @@ struct SceneDev {
     const LightRec* lights;
     int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = LDS ray-stack slots needed
     int32_t has_csg, has_transparency;
+    int32_t csg_entries, pad;  // largest number of list entries a CSG root can produce (LDS list area per lane)
 };
 
 struct CameraDev {

@@ -249,9 +249,14 @@ const uint32_t LBIT = 0x80000000u;
 #ifndef RTX_MIN_WAVES
 #define RTX_MIN_WAVES 4
 #endif
+// scenes with CSG: the hit lists (LDS) and the op interpreter on top of the list walk need more of both
+// LDS and registers per wave, so that variant is built for 3 waves per SIMD (168 VGPRs; 2, 3 and 4 were measured)
+#ifndef RTX_MIN_WAVES_CSG
+#define RTX_MIN_WAVES_CSG 3
+#endif
 
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
+__global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
                                                          unsigned long long* __restrict__ counters) {
@@ -330,8 +335,12 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
     double shadow_dist = 0.0;
 
     // CSG hit list (per lane)
-    double lt[CSG ? RTX_MAX_CSG_ENTRIES : 1];
-    uint32_t ls[CSG ? RTX_MAX_CSG_ENTRIES : 1];
+    // (in LDS, after the ray slots: entry e of this lane at [e * 64 + lane]; sized by the scene's largest CSG
+    // root.  In scratch, every step of the merge loops was a dependent round trip to memory.)
+    double* const lt_ = lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + lane;
+    uint32_t* const ls_ = (uint32_t*)(lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + sc.csg_entries * 64) + lane;
+#define lt(i) lt_[(i) * 64]
+#define ls(i) ls_[(i) * 64]
 
     while (__any(mode != MODE_DONE)) {
         TM(tm_shade);
@@ -415,28 +424,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                 const int R = H_RUN(h);
                 sync_level(level);
                 uint64_t cand = 0;
-                bool live = active;           // lane still wants hits (a shadow ray may be decided mid-run)
-                if (flags & OPF_INLINE) {
-                    // ---- a run of planes (OPF_INLINE): a plane is never culled and every lane tests it, so the
-                    // exact test (plane.rs:16-23, only the y row of the local ray) runs here, wave-uniformly,
-                    // with the row arriving through scalar loads one op ahead
-                    typedef double Row __attribute__((ext_vector_type(4)));
-                    Row row = *(const AS4 Row*)&(bodies + cur)->inv[4];
-                    for (int i = 0; i < R; i++) {
-                        const Row rnext = *(const AS4 Row*)&(bodies + cur + i + 1)->inv[4];   // (array is padded)
-                        const double loy = row[0] * po.x + row[1] * po.y + row[2] * po.z + row[3];
-                        const double ldy = row[0] * pd.x + row[1] * pd.y + row[2] * pd.z;
-                        if (active) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_PLANE, 1); }
-                        if (live) {
-                            EV(RTX_EV_X_XFORM, 1);
-                            if (!(__builtin_fabs(ldy) < 1e-12)) {
-                                feed(1, -loy / ldy, 0.0, cur + i);
-                                if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; live = false; decided = true; }
-                            }
-                        }
-                        row = rnext;
-                    }
-                } else {
+                {
                     // ---- phase 1: conservative bounding-sphere pre-test of every op of the run for every
                     // lane (cull_miss2: no counterpart in the reference, cannot change a result).  Tight
                     // uniform loop over PAIRS of ops (2j, 2j+1): one scalar load of the pair's spheres and
@@ -471,7 +459,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         }
                     }
                 }
-                if (!live) cand = 0;
+                if (!active) cand = 0;
                 EV(RTX_EV_OP_SLOTS, R);
                 TMT(tm_ffwd);
                 // ---- phase 2: every lane walks ITS OWN surviving ops in program order (lowest bit first,
@@ -506,15 +494,10 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                             EV(RTX_EV_X_BOX, 1);
                             if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
                         }
-                        if (CSG && (flags & OPF_LIST)) {
-                            if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
-                            if (k >= 1) { lt[cnt] = t0; ls[cnt] = (uint32_t)idx; cnt++; }
-                            if (k == 2) { lt[cnt] = t1; ls[cnt] = (uint32_t)idx; cnt++; }
-                        } else {
-                            feed(k, t0, t1, idx);
-                            // is_shadowed (world.rs:203-206): any 0 <= t < distance decides
-                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; cand = 0; decided = true; }
-                        }
+                        // (every op under a CSG root carries OPF_LIST: hits go to the per-lane list, in program order)
+                        if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
+                        if (k >= 1) { lt(cnt) = t0; ls(cnt) = (uint32_t)idx; cnt++; }
+                        if (k == 2) { lt(cnt) = t1; ls(cnt) = (uint32_t)idx; cnt++; }
                     }
                 }
                 next = cur + R;
@@ -565,14 +548,14 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                             double* s = lds_rays + (level + 1) * LDS_SLOT_DOUBLES + lane;
                             s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
                             s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
-                            if (CSG && (flags & OPF_LIST)) {
+                            {
                                 const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
                                 starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                             }
                         }
                     }
                 }
-            } else if (CSG && (flags & OPF_LIST) && active) {
+            } else if (active) {
                 const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
                 if (kind == OPK_CSG_MID) {
                     mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
@@ -581,14 +564,14 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                     if (kind == OPK_CSG_END) {
                         // csg.rs:83-90: left_shapes membership == "came from the left child"
                         const int m0 = (int)((mids >> sh) & 0xff);
-                        for (int i = s0; i < cnt; i++) ls[i] = (i < m0) ? (ls[i] | LBIT) : (ls[i] & ~LBIT);
+                        for (int i = s0; i < cnt; i++) ls(i) = (i < m0) ? (ls(i) | LBIT) : (ls(i) & ~LBIT);
                     }
                     // stable sort of the concatenated child lists (intersections.rs:56-59)
                     for (int i = s0 + 1; i < cnt; i++) {
-                        double t = lt[i]; uint32_t id = ls[i];
+                        double t = lt(i); uint32_t id = ls(i);
                         int j = i - 1;
-                        while (j >= s0 && lt[j] > t) { lt[j + 1] = lt[j]; ls[j + 1] = ls[j]; j--; }
-                        lt[j + 1] = t; ls[j + 1] = id;
+                        while (j >= s0 && lt(j) > t) { lt(j + 1) = lt(j); ls(j + 1) = ls(j); j--; }
+                        lt(j + 1) = t; ls(j + 1) = id;
                     }
                     if (kind == OPK_CSG_END) {
                         // filter_intersections (csg.rs:94-121)
@@ -597,7 +580,7 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         int out = s0;
                         for (int i = s0; i < cnt; i++) {
                             EV(RTX_EV_CSG_ENTRIES, 1);
-                            const double t = lt[i]; const uint32_t id = ls[i];
+                            const double t = lt(i); const uint32_t id = ls(i);
                             const bool lhit = (id & LBIT) != 0;
                             bool allowed;                     // csg.rs:123-136
                             if (cop == RTX_CSG_UNION) allowed = (lhit && !inr) || (!lhit && !inl);
@@ -608,15 +591,15 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                                 int size = out - s0, left = 0, right = size, pos = -1;
                                 while (left < right) {
                                     int mid = left + size / 2;
-                                    double tm = lt[s0 + mid];
+                                    double tm = lt(s0 + mid);
                                     if (tm < t) left = mid + 1;
                                     else if (tm > t) right = mid;
                                     else { pos = mid; break; }
                                     size = right - left;
                                 }
                                 if (pos < 0) pos = left;
-                                for (int j = out; j > s0 + pos; j--) { lt[j] = lt[j - 1]; ls[j] = ls[j - 1]; }
-                                lt[s0 + pos] = t; ls[s0 + pos] = id;
+                                for (int j = out; j > s0 + pos; j--) { lt(j) = lt(j - 1); ls(j) = ls(j - 1); }
+                                lt(s0 + pos) = t; ls(s0 + pos) = id;
                                 out++;
                             }
                             if (lhit) inl = !inl; else inr = !inr;
@@ -625,10 +608,10 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
                         if (flags & OPF_ROOT) {
                             // hand the filtered list of this CSG root to the running state
                             for (int i = 0; i < cnt; i++) {
-                                const double t = lt[i]; const int shape = (int)(ls[i] & ~LBIT);
+                                const double t = lt(i); const int shape = (int)(ls(i) & ~LBIT);
                                 int negs = 0;
                                 for (int j = 0; j < cnt; j++)
-                                    if ((int)(ls[j] & ~LBIT) == shape && !(lt[j] >= 0.0)) negs++;
+                                    if ((int)(ls(j) & ~LBIT) == shape && !(lt(j) >= 0.0)) negs++;
                                 if (t >= 0.0) {
                                     if (closer(t, shape)) { best_t = t; best_op = shape; best_inside = (negs == 1); }
                                     break;      // later entries are larger (or tie with a later op)
@@ -1130,6 +1113,8 @@ __global__ __launch_bounds__(64, RTX_MIN_WAVES) void trace_shade_kernel(SceneDev
         }
     }
 #undef EV
+#undef lt
+#undef ls
 }
 
 // ---------------------------------------------------------------- launcher (called by rtx_api.hip)
@@ -1138,7 +1123,7 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
                                              int count_events, hipStream_t stream) {
     const int blocks = rp->tiles_x * rp->n_bands_local;
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double);
+    const size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double) + (size_t)sc->csg_entries * 64 * 12;
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
     if (count_events) {
