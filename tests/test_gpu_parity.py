@@ -104,3 +104,27 @@ def test_errors(ctx):
     with pytest.raises(rtx.RtxError) as e:
         ctx.render(pw, pc[0], 9)
     assert e.value.code == rtx.E_CAPACITY
+
+
+def test_torture_scene_parity(ctx):
+    """Structures the YAML DSL cannot express (tests/torture.py): CSG inside groups, a group as a CSG operand,
+    empty groups, > 32 children per list, a plane inside a group, 5-deep nesting, two lights, glass."""
+    import ora
+    import rtapi
+    import rtx
+    import torture
+    pw, pc = torture.build(rtx.API)
+    ow, oc = torture.build(ora.API)
+    gpu = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+    cpu = ora.render(ow, oc, 5, threads=8)
+    r = parity.assert_parity(gpu, cpu, "torture")
+    gs, cs = gpu["stats"], cpu["stats"]
+    assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), r
+    ge, ce = gs.events(), cs.events()
+    assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}
+    fast = ctx.render(pw, pc, 5)
+    assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"])
+    # an empty world renders black and counts one ray per pixel
+    ew = rtx.API.world_new(); ew.build()
+    e = ctx.render(ew, pc, 5)
+    assert not e["rgb"].any() and (e["hit"] == -1).all() and e["stats"].rays == pc.hsize * pc.vsize
