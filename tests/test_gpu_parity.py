@@ -128,3 +128,22 @@ def test_torture_scene_parity(ctx):
     ew = rtx.API.world_new(); ew.build()
     e = ctx.render(ew, pc, 5)
     assert not e["rgb"].any() and (e["hit"] == -1).all() and e["stats"].rays == pc.hsize * pc.vsize
+
+
+def test_cli_renders_scene_file_to_png(ctx, tmp_path):
+    """main.rs:20-28 end to end: the `rtx` CLI loads a scene file, renders cameras[0] on the GPU and writes
+    <stem>.png into the working directory; the decoded PNG must be the image rtx_render returns."""
+    import os
+    import subprocess
+    from PIL import Image
+    import rtx
+    text = parity.scene_text("S1", 96, 48)
+    scene = tmp_path / "example.yaml"
+    scene.write_text(text)
+    exe = os.path.join(os.path.dirname(rtx.LIB_PATH), "rtx")
+    subprocess.run([exe, str(scene)], check=True, timeout=100, cwd=str(tmp_path))
+    img = np.asarray(Image.open(str(tmp_path / "example.png")))
+    assert img.shape == (48, 96, 3) and img.dtype == np.uint8            # 8-bit RGB (canvas.rs:45-53)
+    pw, pc = rtx.load_yaml(text)
+    want = ctx.render(pw, pc[0], 5)["rgb"]
+    assert np.array_equal(img, want)
