@@ -185,6 +185,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1000.0
         # per launch (= per GPU): each rank's launch does 1/N of the frame's flops in kern_ms (slowest rank)
         achieved = float(counts[3]) / N / (kern_ms / 1000.0) / 1e12
+        traffic = flops.measured_traffic_bytes(args.workload) if (N == 1 and not args.width and not args.height) else None
         out = {
             "metric": "Mrays/sec (primary+shadow+secondary)", "value": rays_frame * args.steps / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -195,7 +196,13 @@ def main():
                        "rays": {"primary": int(counts[0]), "shadow": int(counts[1]), "secondary": int(counts[2])},
                        "parallelism": "row-interleaved 8-row bands x%d + RCCL all-gather" % N if N > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": flops.FP64_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_note": ("L2<->fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB units) from the committed "
+                                          "rocprofv3 --pmc passes profiles/r1d_*_pmc.txt of this workload, not collected by this run; "
+                                          "upper bound with FETCH doubled (gfx950 64-B tally): %d; algorithmic bytes are the %d-byte "
+                                          "image: the rest is the per-lane frame stack and register spills in scratch"
+                                          % (traffic[1], width * height * 3)) if traffic else "not measured for this configuration",
                          "kernel": "trace_shade_kernel", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_frame": float(counts[3]),
                          "executed_f64_flops_per_frame": float(counts[4]),
