@@ -48,10 +48,12 @@ CASES = [
     ("S3", 200, 112, dict(levels=2, per_leaf=6)),
     ("S4", 240, 136, {}),
     ("S5", 240, 136, {}),
+    ("S1", 101, 53, {}),                       # ragged: neither dimension a multiple of the 8x8 tile
+    ("S4", 7, 3, {}),                          # smaller than one tile
 ]
 
 
-@pytest.mark.parametrize("name,w,h,kw", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("name,w,h,kw", CASES, ids=["%s-%dx%d" % c[:3] for c in CASES])
 def test_scene_parity(ctx, name, w, h, kw):
     import ora
     import rtx
