@@ -149,3 +149,44 @@ def test_cli_renders_scene_file_to_png(ctx, tmp_path):
     pw, pc = rtx.load_yaml(text)
     want = ctx.render(pw, pc[0], 5)["rgb"]
     assert np.array_equal(img, want)
+
+
+FULL = [("S2", 1920, 1080), ("S3", 3840, 2160), ("S4", 3840, 2160), ("S5", 7680, 4320)]
+
+
+@pytest.mark.parametrize("name,w,h", FULL, ids=[c[0] for c in FULL])
+def test_full_size_properties_and_sampled_parity(ctx, name, w, h):
+    """BASELINE.json's full sizes: size-independent properties of the frame (determinism, counting
+    identities, same image with and without the shadow early-out) plus parity with the oracle on a seeded
+    sample of 8x8 tiles of the full frame (the oracle traces exactly those pixels)."""
+    import ora
+    import rtx
+    text = parity.scene_text(name, w, h)
+    (pw, pc), (ow, oc) = parity.build_both(text)
+    sc = ctx.scene(pw)
+    try:
+        a = sc.render(pc, 5)
+        b = sc.render(pc, 5)
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"])          # deterministic
+        c = sc.render(pc, 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+        assert np.array_equal(a["rgb"], c["rgb"]) and np.array_equal(a["hit"], c["hit"])
+        st, ev = c["stats"], c["stats"].events()
+        n_lights = text.count("- add: light")
+        assert st.rays_primary == w * h
+        assert st.rays_shadow == ev["light"] == n_lights * ev["hit"]                              # world.rs:129-136
+        assert (a["stats"].rays_primary, a["stats"].rays_shadow, a["stats"].rays_secondary) == \
+            (st.rays_primary, st.rays_shadow, st.rays_secondary)
+        assert int((a["hit"] >= 0).sum()) <= ev["hit"]
+        rng = np.random.default_rng(20261111)
+        tx, ty = (w + 7) // 8, (h + 7) // 8
+        tiles = rng.choice(tx * ty, 48, replace=False)
+        xs, ys = [], []
+        for t in tiles:
+            gx, gy = np.meshgrid(np.arange((t % tx) * 8, min((t % tx) * 8 + 8, w)), np.arange((t // tx) * 8, min((t // tx) * 8 + 8, h)))
+            xs.append(gx.ravel()); ys.append(gy.ravel())
+        xs, ys = np.concatenate(xs), np.concatenate(ys)
+        cpu = ora.render(ow, oc, 5, pixels=(xs, ys), threads=8)
+        gpu = dict(rgb=a["rgb"][ys, xs][None], hit=a["hit"][ys, xs][None])
+        parity.assert_parity(gpu, dict(rgb=cpu["rgb"][None], hit=cpu["hit"][None], tie=cpu["tie"][None]), name + " full-size sample")
+    finally:
+        sc.close()
