@@ -556,6 +556,17 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
     rp.max_depth = max_depth; rp.band_first = bands.first; rp.band_stride = bands.stride;
     rp.n_bands_local = local_bands(cam->vsize, bands);
     rp.tiles_x = (cam->hsize + RTX_TILE - 1) / RTX_TILE;
+    {
+        // a multiplier coprime with the tile count (default 7919; RTX_TILE_MUL overrides for experiments)
+        const long long n_tiles = (long long)rp.tiles_x * rp.n_bands_local;
+        const char* e = getenv("RTX_TILE_MUL");
+        long long m = e ? atoll(e) : 7919;
+        auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
+        if (m < 1) m = 1;
+        while (n_tiles > 1 && gcd(m % n_tiles ? m % n_tiles : n_tiles, n_tiles) != 1) m++;
+        rp.tile_mul = (int)(n_tiles > 0 ? m % (n_tiles > 1 ? n_tiles : 2) : 1);
+        if (rp.tile_mul == 0) rp.tile_mul = 1;
+    }
     rp.compact = (flags & RTX_F_BANDS_COMPACT) ? 1 : 0;
     rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
 

@@ -145,7 +145,8 @@ struct RenderParams {
     int32_t tiles_x;
     int32_t compact;          // write bands back-to-back
     int32_t no_early_out;
-    int32_t pad;
+    int32_t tile_mul;         // block b renders tile (b * tile_mul) mod n_tiles: coprime with n_tiles, spreads heavy image
+                              //   regions over the whole dispatch instead of leaving them to the tail
 };
 
 // counters[]: 0 radiance rays, 1 shadow rays, 2 overflow pixels, 3.. events

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                                                          unsigned long long* __restrict__ counters) {
     extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
     const int tx = tile % rp.tiles_x, bl = tile / rp.tiles_x;
     const int band = rp.band_first + bl * rp.band_stride;
 
