@@ -199,7 +199,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_note": ("L2<->fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB units) from the committed "
-                                          "rocprofv3 --pmc passes profiles/r1d_*_pmc.txt of this workload, not collected by this run; "
+                                          "rocprofv3 --pmc passes profiles/r1e_*_pmc.txt of this workload, not collected by this run; "
                                           "upper bound with FETCH doubled (gfx950 64-B tally): %d; algorithmic bytes are the %d-byte "
                                           "image: the rest is the per-lane frame stack and register spills in scratch"
                                           % (traffic[1], width * height * 3)) if traffic else "not measured for this configuration",
