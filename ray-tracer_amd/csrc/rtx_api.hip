@@ -369,7 +369,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, RTX_CNT_TOTAL * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return RTX_E_DEVICE;
     }
@@ -572,15 +572,18 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, RTX_CNT_TOTAL * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long), st));
     if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
     HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &rp, (uint8_t*)d_rgb, (int32_t*)d_hit, ctx->d_counters,
                                        (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, st));
     if (stats) {
         HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
-        unsigned long long h[RTX_CNT_TOTAL];
-        HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
+        std::vector<unsigned long long> rep((size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE);
+        HIPCHK(ctx, hipMemcpyAsync(rep.data(), ctx->d_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
+        unsigned long long h[RTX_CNT_TOTAL] = {0};
+        for (int sl = 0; sl < RTX_CNT_SLOTS; sl++)
+            for (int k = 0; k < RTX_CNT_TOTAL; k++) h[k] += rep[(size_t)sl * RTX_CNT_STRIDE + k];
         float ms = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         std::memset(stats, 0, sizeof *stats);

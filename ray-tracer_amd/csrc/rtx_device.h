@@ -155,5 +155,11 @@ struct RenderParams {
 #define RTX_CNT_OVERFLOW 2
 #define RTX_CNT_EV0 3
 #define RTX_CNT_TOTAL (3 + 24)
+// The counters are replicated over RTX_CNT_SLOTS slots of RTX_CNT_STRIDE entries (256 bytes, own cache lines);
+// a wave adds into slot (block index mod RTX_CNT_SLOTS) and the host sums the slots.  With ONE set of
+// counters every wave's two ray-count atomics hit the same address and serialise at ~12 ns each: a floor of
+// 3.1 ms for the 129 600 waves of a 4K frame (measured; it bounded S2, S3 and S5).
+#define RTX_CNT_SLOTS 256
+#define RTX_CNT_STRIDE 32
 
 #endif

@@ -259,7 +259,8 @@ template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
-                                                         unsigned long long* __restrict__ counters) {
+                                                         unsigned long long* __restrict__ counters_base) {
+    unsigned long long* counters = counters_base;
     extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
     const int lane = threadIdx.x;
     const int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
@@ -1090,6 +1091,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 
 #ifdef RTX_TIMING
     if (lane == 0) {
+        unsigned long long* counters = counters_base + (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;
         atomicAdd(&counters[RTX_CNT_EV0 + 18], tm_ffwd);
         atomicAdd(&counters[RTX_CNT_EV0 + 19], tm_body);
         atomicAdd(&counters[RTX_CNT_EV0 + 20], tm_shade);
@@ -1100,6 +1102,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 #endif
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow);
+    counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
     if (lane == 0) {
         atomicAdd(&counters[RTX_CNT_RADIANCE], (unsigned long long)t0);
         atomicAdd(&counters[RTX_CNT_SHADOW], (unsigned long long)t1);
