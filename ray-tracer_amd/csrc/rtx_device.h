@@ -128,7 +128,7 @@ struct SceneDev {
     const LightRec* lights;
     int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = LDS ray-stack slots needed
     int32_t has_csg, has_transparency;
-    int32_t csg_entries, pad;  // largest number of list entries a CSG root can produce (LDS list area per lane)
+    int32_t csg_entries, has_branching;  // has_branching: some material is reflective AND transparent (two children per hit)  // largest number of list entries a CSG root can produce (LDS list area per lane)
 };
 
 struct CameraDev {
@@ -145,6 +145,13 @@ struct RenderParams {
     int32_t tiles_x;
     int32_t compact;          // write bands back-to-back
     int32_t no_early_out;
+    // expensive-tiles-first order (rtx_api.hip): a PROBE launch traces the centre pixel of every tile at depth
+    // budget 2 and appends the tile to one of RTX_TILE_CLASSES lists by the rays that took; the frame launch
+    // maps block b to the b-th tile of the concatenation, most expensive class first.
+    int32_t* tile_lists;       // RTX_TILE_CLASSES x n_tiles tile indices (class k at [k * n_tiles ...])
+    int32_t* tile_counts;      // RTX_TILE_CLASSES list lengths (one 32-byte line)
+    int32_t super_mul, pad1;   // probe launch: block b probes the 8x8 block of tiles (b * super_mul) mod n_super
+    int32_t probe, use_lists;  // probe: this IS the probe launch (no image, no counters); use_lists: follow the lists
     int32_t tile_mul;         // block b renders tile (b * tile_mul) mod n_tiles: coprime with n_tiles, spreads heavy image
                               //   regions over the whole dispatch instead of leaving them to the tail
 };
@@ -159,6 +166,7 @@ struct RenderParams {
 // a wave adds into slot (block index mod RTX_CNT_SLOTS) and the host sums the slots.  With ONE set of
 // counters every wave's two ray-count atomics hit the same address and serialise at ~12 ns each: a floor of
 // 3.1 ms for the 129 600 waves of a 4K frame (measured; it bounded S2, S3 and S5).
+#define RTX_TILE_CLASSES 8
 #define RTX_CNT_SLOTS 256
 #define RTX_CNT_STRIDE 32
 

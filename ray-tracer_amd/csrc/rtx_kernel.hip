@@ -263,7 +263,17 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     unsigned long long* counters = counters_base;
     extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
     const int lane = threadIdx.x;
-    const int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
+    int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
+    if (rp.use_lists) {
+        // block b -> b-th tile of the class lists, most expensive class first (the probe launch filled them)
+        typedef int32_t I8 __attribute__((ext_vector_type(8)));
+        const I8 cnt = *(const AS4 I8*)(uintptr_t)rp.tile_counts;
+        int rest = (int)blockIdx.x, k = RTX_TILE_CLASSES - 1;
+#pragma unroll
+        for (int q = RTX_TILE_CLASSES - 1; q > 0; q--)
+            if (k == q && rest >= cnt[q]) { rest -= cnt[q]; k = q - 1; }
+        tile = ((const AS4 int32_t*)(uintptr_t)rp.tile_lists)[(size_t)k * (rp.tiles_x * rp.n_bands_local) + rest];
+    }
     const int tx = tile % rp.tiles_x, bl = tile / rp.tiles_x;
     const int band = rp.band_first + bl * rp.band_stride;
 
@@ -299,9 +309,20 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     int mode;
     // ---- Camera::ray_for_pixel (camera.rs:56-69); the ray goes to LDS slot 0
     {
-        const int px = tx * RTX_TILE + (lane & 7);
-        const int py = band * RTX_TILE + (lane >> 3);
+        int px = tx * RTX_TILE + (lane & 7);
+        int py = band * RTX_TILE + (lane >> 3);
         mode = (px < cam.hsize && py < cam.vsize) ? MODE_RADIANCE : MODE_DONE;
+        if (rp.probe) {
+            // probe launch: one wave per 8x8 block of TILES (so its 64 rays stay coherent), lane -> centre pixel of a tile
+            const int sx_n = (rp.tiles_x + 7) >> 3;
+            const int sb = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.super_mul) % (unsigned)(sx_n * ((rp.n_bands_local + 7) >> 3)));
+            const int ptx = (sb % sx_n) * 8 + (lane & 7), pbl = (sb / sx_n) * 8 + (lane >> 3);
+            px = ptx * RTX_TILE + 4;
+            py = (rp.band_first + pbl * rp.band_stride) * RTX_TILE + 4;
+            mode = (ptx < rp.tiles_x && pbl < rp.n_bands_local) ? MODE_RADIANCE : MODE_DONE;
+            px = px < cam.hsize ? px : cam.hsize - 1;
+            py = py < cam.vsize ? py : cam.vsize - 1;
+        }
         double xoffset = ((double)px + 0.5) * cam.pixel_size;
         double yoffset = ((double)py + 0.5) * cam.pixel_size;
         double world_x = cam.half_width - xoffset;
@@ -840,7 +861,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         if (mode == MODE_RADIANCE) {
             if (primary) {
                 primary = false;
-                if (hit_out) {
+                if (hit_out && !rp.probe) {
                     const int px = tx * RTX_TILE + (lane & 7);
                     const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : (band * RTX_TILE + (lane >> 3));
                     hit_out[(size_t)row * cam.hsize + px] = best_op >= 0 ? sc.hits[best_op].shape : -1;
@@ -1038,7 +1059,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // ---- unwind: hand finished colours to the waiting frames (post-order)
         while (returning) {
             if (sp == 0) {
-                write_pixel(rr, rg, rb);
+                if (!rp.probe) write_pixel(rr, rg, rb);
                 mode = MODE_DONE;
                 returning = false;
             } else {
@@ -1100,6 +1121,42 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         atomicAdd(&counters[RTX_CNT_EV0 + 23], tm_light);
     }
 #endif
+    if (rp.probe) {
+        // probe launch: the rays this tile's centre pixel needed at the reduced depth -> cost class of the tile;
+        // one list append per wave and class (wave-aggregated atomic)
+        const int n_tiles = rp.tiles_x * rp.n_bands_local;
+        const int sx_n = (rp.tiles_x + 7) >> 3;
+        const int sb = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.super_mul) % (unsigned)(sx_n * ((rp.n_bands_local + 7) >> 3)));
+        const int ptx = (sb % sx_n) * 8 + (lane & 7), pbl = (sb / sx_n) * 8 + (lane >> 3);
+        const bool pvalid = ptx < rp.tiles_x && pbl < rp.n_bands_local;
+        // a tile next to an expensive one (the silhouette of a glass object) is probably expensive in a corner
+        // its own centre pixel does not see: take the maximum over the 3x3 neighbourhood inside this wave's block
+        int c = pvalid ? (int)(n_radiance + n_shadow) : 0;
+        {
+            const int l = __shfl(c, lane - 1, 64), r = __shfl(c, lane + 1, 64);
+            int h = c;
+            if ((lane & 7) > 0 && l > h) h = l;
+            if ((lane & 7) < 7 && r > h) h = r;
+            const int u = __shfl(h, lane - 8, 64), d = __shfl(h, lane + 8, 64);
+            c = h;
+            if (lane >= 8 && u > c) c = u;
+            if (lane < 56 && d > c) c = d;
+        }
+        int cls = c >> 1;
+        cls = cls > RTX_TILE_CLASSES - 1 ? RTX_TILE_CLASSES - 1 : cls;
+        if (!pvalid) cls = -1;
+        const int t = pbl * rp.tiles_x + ptx;
+        for (int k = 0; k < RTX_TILE_CLASSES; k++) {
+            const unsigned long long m = __ballot(cls == k);
+            if (m == 0) continue;
+            const int leader = (int)__builtin_ctzll(m);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&rp.tile_counts[k], (int)__builtin_popcountll(m));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == k) rp.tile_lists[(size_t)k * n_tiles + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+        }
+        return;
+    }
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
@@ -1124,7 +1181,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
                                              int count_events, hipStream_t stream) {
-    const int blocks = rp->tiles_x * rp->n_bands_local;
+    const int blocks = rp->probe ? ((rp->tiles_x + 7) / 8) * ((rp->n_bands_local + 7) / 8) : rp->tiles_x * rp->n_bands_local;
     if (blocks <= 0) return hipSuccess;
     const size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double) + (size_t)sc->csg_entries * 64 * 12;
     dim3 grid(blocks), block(64);

@@ -190,3 +190,25 @@ def test_full_size_properties_and_sampled_parity(ctx, name, w, h):
         parity.assert_parity(gpu, dict(rgb=cpu["rgb"][None], hit=cpu["hit"][None], tie=cpu["tie"][None]), name + " full-size sample")
     finally:
         sc.close()
+
+
+def test_tile_order_does_not_change_the_image(ctx, monkeypatch):
+    """The expensive-tiles-first order (probe launch + class lists, rtx_api.hip) is scheduling only: forced on and
+    forced off must give the same image, hit ids and ray counts, also for ragged sizes and band subsets."""
+    import rtx
+    text = parity.scene_text("S4", 333, 171)
+    pw, pc = rtx.load_yaml(text)
+    sc = ctx.scene(pw)
+    try:
+        monkeypatch.setenv("RTX_LPT", "0")
+        a = sc.render(pc[0], 5)
+        monkeypatch.setenv("RTX_LPT", "1")
+        b = sc.render(pc[0], 5)
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"])
+        assert a["stats"].rays == b["stats"].rays
+        rgb = np.zeros_like(a["rgb"]); hit = np.full_like(a["hit"], -7)
+        for g in range(3):
+            sc.render(pc[0], 5, bands=(g, 3), out=(rgb, hit))
+        assert np.array_equal(rgb, a["rgb"]) and np.array_equal(hit, a["hit"])
+    finally:
+        sc.close()

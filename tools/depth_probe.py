@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""Renders S4 at depth budgets 0, 1, 5 (3 launches each) so PMC passes can attribute traffic to the frame stack."""
+"""Renders a workload at depth budgets 0, 1, 2, 5 and prints time, rays and (diagnostic builds) the section timers."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ray-tracer_amd", "python"), os.path.join(ROOT, "tools")]
 import rtx, scenes
+from bench import WORKLOADS
+name = sys.argv[1] if len(sys.argv) > 1 else "S4"
+sn, w, h, _ = WORKLOADS[name]
 ctx = rtx.Context(0)
-world, cams = rtx.load_yaml(scenes.make("S4", width=3840, height=2160))
+world, cams = rtx.load_yaml(scenes.make(sn, width=w, height=h))
 sc = ctx.scene(world)
-for depth in (0, 1, 5):
+for depth in (0, 1, 2, 5):
     for _ in range(3):
         r = sc.render(cams[0], depth, want_hit=False)
-    print(depth, r["stats"].rays, round(r["stats"].kernel_ms, 3), flush=True)
+    c = sc.render(cams[0], depth, want_hit=False, flags=rtx.F_COUNT_EVENTS)["stats"].events()
+    st = r["stats"]
+    t = [int(st.ev[i]) for i in range(18, 24)]
+    wi = c["lane_slots"] / 64
+    print(depth, st.rays, round(st.kernel_ms, 3), "wave-iters %d" % wi, "packing %.3f" % (st.rays / c["lane_slots"]),
+          "cycles/wave-iter:", dict(zip(["cullORsetup", "exactORchildren", "shadeORunwind", "otherORtrav", "prep", "light"], [round(x / wi) for x in t])), flush=True)
