@@ -185,6 +185,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1000.0
         # per launch (= per GPU): each rank's launch does 1/N of the frame's flops in kern_ms (slowest rank)
         achieved = float(counts[3]) / N / (kern_ms / 1000.0) / 1e12
+        executed = float(counts[4]) / N / (kern_ms / 1000.0) / 1e12
         traffic = flops.measured_traffic_bytes(args.workload) if (N == 1 and not args.width and not args.height) else None
         out = {
             "metric": "Mrays/sec (primary+shadow+secondary)", "value": rays_frame * args.steps / elapsed / 1e6,
@@ -199,7 +200,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_note": ("L2<->fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB units) from the committed "
-                                          "rocprofv3 --pmc passes profiles/r1e_*_pmc.txt of this workload, not collected by this run; "
+                                          "rocprofv3 --pmc passes profiles/r1f_S4_pmc.txt / r1e_*_pmc.txt of this workload, not collected by this run; "
                                           "upper bound with FETCH doubled (gfx950 64-B tally): %d; algorithmic bytes are the %d-byte "
                                           "image: the rest is the per-lane frame stack and register spills in scratch"
                                           % (traffic[1], width * height * 3)) if traffic else "not measured for this configuration",
@@ -208,10 +209,14 @@ def main():
                          "executed_f64_flops_per_frame": float(counts[4]),
                          "node_visits": {"reference_defined": int(counts[7]), "f32_pre_tests": int(counts[5]),
                                          "exact_f64_tests": int(counts[6])},
-                         "frac_of_unfused_ceiling": achieved / flops.FP64_UNFUSED_PEAK_TFLOPS,
-                         "note": "path is FP64-VALU bound (SURVEY.md 8d): no dense contraction (no MFMA), scene is "
-                                 "L2-resident (HBM traffic = output image only); kernel_ms = slowest rank's average "
-                                 "launch time from HIP events on the launch stream"},
+                         "executed": {"f64_tflops": executed, "frac_of_peak": executed / flops.FP64_VECTOR_PEAK_TFLOPS,
+                                      "frac_of_unfused_ceiling": executed / flops.FP64_UNFUSED_PEAK_TFLOPS},
+                         "note": "achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events x "
+                                 "the survey's flop constants / kernel time; the conservative pre-tests (f32 bounding spheres, "
+                                 "interval filter) answer most node visits without the f64 arithmetic, so this figure is not bounded "
+                                 "by the ALU peak (it is the flop-equivalent of Mrays/s).  `executed` is the f64 work really issued "
+                                 "against the same peak.  No dense contraction, so no MFMA; kernel_ms = slowest rank's average launch "
+                                 "time from HIP events on the launch stream (includes the tile-order probe launch when used)"},
         }
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, width, height)

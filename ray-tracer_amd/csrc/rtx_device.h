@@ -166,7 +166,9 @@ struct RenderParams {
 // a wave adds into slot (block index mod RTX_CNT_SLOTS) and the host sums the slots.  With ONE set of
 // counters every wave's two ray-count atomics hit the same address and serialise at ~12 ns each: a floor of
 // 3.1 ms for the 129 600 waves of a 4K frame (measured; it bounded S2, S3 and S5).
+#ifndef RTX_TILE_CLASSES
 #define RTX_TILE_CLASSES 8
+#endif
 #define RTX_CNT_SLOTS 256
 #define RTX_CNT_STRIDE 32
 

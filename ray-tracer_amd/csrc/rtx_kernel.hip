@@ -255,7 +255,9 @@ const uint32_t LBIT = 0x80000000u;
 #define RTX_MIN_WAVES_CSG 3
 #endif
 
-template <bool CSG, bool COUNT>
+// PROBE: the tile-cost probe launch (rtx_api.hip) — same code, but lanes map to tile centres, nothing is written
+// to the image or the counters, and the rays needed file the tile into a cost class
+template <bool CSG, bool COUNT, bool PROBE = false>
 __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
@@ -264,9 +266,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
     const int lane = threadIdx.x;
     int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
-    if (rp.use_lists) {
+    if (!PROBE && rp.use_lists) {
         // block b -> b-th tile of the class lists, most expensive class first (the probe launch filled them)
-        typedef int32_t I8 __attribute__((ext_vector_type(8)));
+        typedef int32_t I8 __attribute__((ext_vector_type(RTX_TILE_CLASSES)));
         const I8 cnt = *(const AS4 I8*)(uintptr_t)rp.tile_counts;
         int rest = (int)blockIdx.x, k = RTX_TILE_CLASSES - 1;
 #pragma unroll
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         int px = tx * RTX_TILE + (lane & 7);
         int py = band * RTX_TILE + (lane >> 3);
         mode = (px < cam.hsize && py < cam.vsize) ? MODE_RADIANCE : MODE_DONE;
-        if (rp.probe) {
+        if (PROBE) {
             // probe launch: one wave per 8x8 block of TILES (so its 64 rays stay coherent), lane -> centre pixel of a tile
             const int sx_n = (rp.tiles_x + 7) >> 3;
             const int sb = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.super_mul) % (unsigned)(sx_n * ((rp.n_bands_local + 7) >> 3)));
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         if (mode == MODE_RADIANCE) {
             if (primary) {
                 primary = false;
-                if (hit_out && !rp.probe) {
+                if (hit_out && !PROBE) {
                     const int px = tx * RTX_TILE + (lane & 7);
                     const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : (band * RTX_TILE + (lane >> 3));
                     hit_out[(size_t)row * cam.hsize + px] = best_op >= 0 ? sc.hits[best_op].shape : -1;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // ---- unwind: hand finished colours to the waiting frames (post-order)
         while (returning) {
             if (sp == 0) {
-                if (!rp.probe) write_pixel(rr, rg, rb);
+                if (!PROBE) write_pixel(rr, rg, rb);
                 mode = MODE_DONE;
                 returning = false;
             } else {
@@ -1121,7 +1123,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         atomicAdd(&counters[RTX_CNT_EV0 + 23], tm_light);
     }
 #endif
-    if (rp.probe) {
+    if (PROBE) {
         // probe launch: the rays this tile's centre pixel needed at the reduced depth -> cost class of the tile;
         // one list append per wave and class (wave-aggregated atomic)
         const int n_tiles = rp.tiles_x * rp.n_bands_local;
@@ -1142,7 +1144,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             if (lane >= 8 && u > c) c = u;
             if (lane < 56 && d > c) c = d;
         }
-        int cls = c >> 1;
+        int cls = RTX_TILE_CLASSES == 8 ? (c >> 1) : c;
         cls = cls > RTX_TILE_CLASSES - 1 ? RTX_TILE_CLASSES - 1 : cls;
         if (!pvalid) cls = -1;
         const int t = pbl * rp.tiles_x + ptx;
@@ -1186,7 +1188,10 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
     const size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double) + (size_t)sc->csg_entries * 64 * 12;
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
-    if (count_events) {
+    if (rp->probe) {
+        if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+        else     hipLaunchKernelGGL((trace_shade_kernel<false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+    } else if (count_events) {
         if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
         else     hipLaunchKernelGGL((trace_shade_kernel<false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
     } else {

@@ -51,7 +51,7 @@ FP64_UNFUSED_PEAK_TFLOPS = 39.3    # one flop per lane-issue: the ceiling for pa
 
 
 # L2 <-> fabric traffic of one trace_shade_kernel launch at the bench's default size on ONE GPU, from separate
-# rocprofv3 --pmc passes (tools/pmc_passes.sh; summaries in profiles/r1e_*_pmc.txt).  Units: the counters
+# rocprofv3 --pmc passes (tools/pmc_passes.sh; summaries in profiles/r1e_*_pmc.txt, r1f for S4).  Units: the counters
 # report KiB (checked against a 24 883 200-byte fill in the same trace: WRITE_SIZE 24300.0).  FETCH_SIZE on
 # gfx950 tallies 128-B requests at 64 B for wide coalesced reads and is uncalibrated for other widths
 # (MI355X_MICROARCH.md, HBM); this kernel's fabric reads are scratch re-loads (4-16 B per lane), so FETCH is
@@ -59,7 +59,7 @@ FP64_UNFUSED_PEAK_TFLOPS = 39.3    # one flop per lane-issue: the ceiling for pa
 # quotes these numbers only for the exact workload they were measured on.
 MEASURED_TRAFFIC_KIB = {          # workload: (FETCH_SIZE, WRITE_SIZE) per launch
     "S3": (63663, 688858),
-    "S4": (2384549, 6802046),
+    "S4": (2670007, 7179379),      # frame launch + tile-order probe launch (profiles/r1f_S4_pmc.txt)
     "S5": (427135, 8269739),
 }
 
