@@ -588,7 +588,7 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
     {
         const int n_tiles = rp.tiles_x * rp.n_bands_local;
         const char* e = getenv("RTX_LPT");
-        const bool want = e ? atoi(e) != 0 : (max_depth >= 1 && n_tiles >= 16384 && scene->dev.has_branching);
+        const bool want = e ? atoi(e) != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching);
         if (want && n_tiles > 0) {
             if (ctx->tile_cap < (size_t)n_tiles) {
                 if (ctx->d_lists) (void)hipFree(ctx->d_lists);
