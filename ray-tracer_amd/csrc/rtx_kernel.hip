@@ -9,14 +9,16 @@
 //      reflected/refracted_color (:151-193), schlick (:304-323) -> Color::to_rgb (color.rs:40-48).
 //
 // Design:
-//  * all arithmetic f64 in the reference's operation order; built with -ffp-contract=off
-//    (Rust never fuses a*b+c), IEEE division and sqrt.
-//  * the scene is a linear traversal program walked wave-uniformly (rtx_device.h); node records
-//    arrive through scalar loads and are consumed as SGPR operands of the f64 VALU ops.
+//  * all geometry and shading arithmetic f64 in the reference's operation order; built with
+//    -ffp-contract=off (Rust never fuses a*b+c), IEEE division and sqrt (one exception: rtx_pow.h).
+//  * outside CSG the wave walks the scene's child lists together (rtx_device.h: ListChunk/ContRec):
+//    per chunk one packed-f32 bounding-sphere sweep for all lanes, then per-lane exact f64 tests of
+//    each lane's own candidates, then only the containers some lane may hit.  Under a CSG root an op
+//    interpreter walks the ops in program order (hit lists need the reference's order).
 //  * no hit lists outside CSG subtrees: closest hit / shadow / refractive containers are O(1)
 //    running state that is provably equal to the reference's sorted Vec.
-//    Under a CSG root a bounded per-lane list (RTX_MAX_CSG_ENTRIES) is built, stably merged and
-//    filtered exactly like csg.rs:73-136.
+//    Under a CSG root a bounded per-lane list (RTX_MAX_CSG_ENTRIES, in LDS) is built, stably merged
+//    and filtered exactly like csg.rs:73-136.
 //  * recursion (world.rs:160,190) becomes a per-lane state machine with an explicit post-order
 //    frame stack of max_depth frames; every lane always traces *some* ray (radiance or shadow)
 //    in the shared traversal, so reflection/refraction divergence does not idle lanes.
