@@ -1,14 +1,14 @@
 // rtx_device.h — device-side scene layout shared by the scene compiler
 // (rtx_api.hip) and the kernel (rtx_kernel.hip).
 //
-// The scene graph (object_store.rs / group.rs / csg.rs) is compiled into a linear
-// TRAVERSAL PROGRAM: the nodes in the reference's depth-first visiting order
-// (world.rs:113, group.rs:70, csg.rs:80-81) with explicit BEGIN/MID/END records for
-// containers.  A whole wavefront walks the program together (the op index is
-// wave-uniform, so records are fetched with scalar loads into SGPRs); lanes that
-// failed a container's bounds test sit out until the op index reaches their
-// `resume_at`.  Visiting order == reference order, so "first hit wins ties"
-// reproduces the stable sorts of intersections.rs:53,58 without any list.
+// The scene graph (object_store.rs / group.rs / csg.rs) is compiled into
+//  * a linear TRAVERSAL PROGRAM: the nodes in the reference's depth-first visiting order (world.rs:113,
+//    group.rs:70, csg.rs:80-81) with explicit BEGIN/MID/END records for containers.  The op index is the
+//    identity of a shape inside the kernel and equals the visiting order, so "smallest (t, op index) wins"
+//    reproduces the stable sorts of intersections.rs:53,58 without any list.  The op interpreter walks the
+//    ops of a CSG root (wave-uniform op index, records through scalar loads; lanes that failed a nested
+//    container's bounds test sit out until the op index reaches their `resume_at`);
+//  * CHILD LISTS (ListChunk / ContRec below) for everything outside CSG, which the kernel walks list by list.
 #ifndef RTX_DEVICE_H
 #define RTX_DEVICE_H
 #include <stdint.h>
