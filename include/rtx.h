@@ -111,7 +111,7 @@ typedef struct rtx_stats {
     uint64_t rays_primary, rays_shadow, rays_secondary;   /* 1 per color_at (world.rs:100) / is_shadowed (world.rs:195) */
     uint64_t ev[RTX_EV_COUNT];           /* filled only with RTX_F_COUNT_EVENTS */
     uint64_t overflow_pixels;            /* pixels that hit a bounded-list limit (then RTX_E_CAPACITY) */
-    double   kernel_ms;                  /* hipEvent time of the trace_shade launch */
+    double   kernel_ms;                  /* hipEvent time of the launches of this render (tile-order probe, when used, + frame) */
 } rtx_stats;
 
 /* render flags */
