@@ -120,6 +120,16 @@ def main():
         else:
             parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(world_size)]
             dist.all_gather(parts, inp.cpu()); out.copy_(torch.cat(parts))
+
+    class _Done:                     # stand-in for a finished collective (the gloo rehearsal gathers synchronously)
+        def wait(self):
+            return True
+
+    def all_gather_async(out, inp):
+        if backend == "nccl":
+            return dist.all_gather_into_tensor(out, inp, async_op=True)
+        all_gather(out, inp)
+        return _Done()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -163,13 +173,33 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # N > 1 over RCCL: frame k's all-gather runs on RCCL's stream while frame k+1 renders on the compute stream
+    # (two band buffers, two frame buffers); a buffer is reused only after its own gather has been waited for.
+    overlap = N > 1 and os.environ.get("RTX_BENCH_OVERLAP", "1") != "0"
+    if overlap:
+        locals_ = [local, torch.zeros_like(local)]
+        frames_ = [gathered, torch.zeros_like(gathered)]
+        pending = [None, None]
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if overlap:
+            b = k & 1
+            if pending[b] is not None:
+                pending[b].wait()                 # stream-level: the compute stream waits for that gather
+            ev[k][0].record()
+            scene.render_device(cam, locals_[b].data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
+            ev[k][1].record()
+            pending[b] = all_gather_async(frames_[b], locals_[b])
+            continue
         ev[k][0].record()
         scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
         ev[k][1].record()
         if N > 1:
             all_gather(gathered, local)
+    if overlap:
+        for w in pending:
+            if w is not None:
+                w.wait()
     torch.cuda.synchronize()
     if N > 1:
         dist.barrier()
@@ -195,7 +225,7 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, desc), "width": width, "height": height,
                        "max_depth": 5, "rays_per_frame": rays_frame,
                        "rays": {"primary": int(counts[0]), "shadow": int(counts[1]), "secondary": int(counts[2])},
-                       "parallelism": "row-interleaved 8-row bands x%d + RCCL all-gather" % N if N > 1 else "1 GPU"},
+                       "parallelism": ("row-interleaved 8-row bands x%d + RCCL all-gather%s" % (N, " overlapped with the next frame" if overlap else "")) if N > 1 else "1 GPU"},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": flops.FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic[0] if traffic else None,
