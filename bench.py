@@ -147,7 +147,11 @@ def main():
     assert rows_local <= rows_pad
     local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(N * rows_pad * width * 3, dtype=torch.uint8, device=dev) if N > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) stream for everything below: the kernel launches, the timing events and the streams RCCL
+    # synchronises with are then one and the same queue (the null stream would hand the C ABI its own stream)
+    compute = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(compute)
+    stream = compute.cuda_stream
 
     def step(stats=False):
         st = scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, stats)
