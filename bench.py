@@ -243,6 +243,7 @@ def main():
                          "executed_f64_flops_per_frame": float(counts[4]),
                          "node_visits": {"reference_defined": int(counts[7]), "f32_pre_tests": int(counts[5]),
                                          "exact_f64_tests": int(counts[6])},
+                         "valu_busy_pmc": flops.MEASURED_VALU_BUSY.get(args.workload) if traffic else None,
                          "executed": {"f64_tflops": executed, "frac_of_peak": executed / flops.FP64_VECTOR_PEAK_TFLOPS,
                                       "frac_of_unfused_ceiling": executed / flops.FP64_UNFUSED_PEAK_TFLOPS},
                          "note": "achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events x "

@@ -70,3 +70,8 @@ def measured_traffic_bytes(workload):
     if t is None:
         return None
     return (t[0] + t[1]) * 1024, (2 * t[0] + t[1]) * 1024
+
+
+# VALU pipe utilisation of the frame launch from the same committed PMC passes:
+# SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
+MEASURED_VALU_BUSY = {"S4": 0.71}
