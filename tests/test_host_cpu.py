@@ -177,3 +177,155 @@ def test_scene_desc_validation_needs_no_gpu():
     assert rtx.LIB.rtx_band_rows(100, rtx.Bands(0, 1)) == 104
     assert rtx.LIB.rtx_band_rows(100, rtx.Bands(1, 2)) == 48 and rtx.LIB.rtx_band_rows(100, rtx.Bands(0, 2)) == 56
     assert rtx.LIB.rtx_strerror(rtx.E_CAPACITY) is not None
+
+
+# ---------------------------------------------------------------- loader fuzz
+def _fz_num(rng, ints=True):
+    k = int(rng.integers(0, 8))
+    if k == 0 and ints:
+        return str(int(rng.integers(-5, 6)))
+    if k == 1:
+        return "%.17g" % float(rng.uniform(-5, 5))
+    if k == 2:
+        return ["pi / 2", "pi / 3.", "-pi / 4", "pi * 0.25", "1. / pi", "2 * pi", "pi - 1", "0.5 + 0.25"][int(rng.integers(0, 8))]
+    if k == 3:
+        return ["1e-1", "2.5E+0", ".5", "3.", "+2", "-0.0", "0x2", "1 + 2 3"][int(rng.integers(0, 8))]
+    return "%.6g" % float(rng.uniform(0.1, 3))
+
+
+def _fz_tuple(rng):
+    sp = ["", " "][int(rng.integers(0, 2))]
+    return "[" + ("," + sp).join(_fz_num(rng) for _ in range(3)) + "]"
+
+
+def _fz_transform(rng, ind):
+    lines = []
+    for _ in range(int(rng.integers(1, 5))):
+        k = ["scale", "translate", "rotate-x", "rotate-y", "rotate-z", "shear"][int(rng.integers(0, 6))]
+        v = _fz_tuple(rng) if k in ("scale", "translate", "shear") else _fz_num(rng)
+        lines.append("%s- %s: %s" % (ind, k, v))
+    return lines
+
+
+def _fz_material_keys(rng, ind, names):
+    keys = []
+    for k in rng.permutation(["color", "pattern", "ambient", "diffuse", "specular", "shininess", "reflective",
+                              "transparency", "refractive-index", "extends", "colour"]):
+        if rng.random() < 0.45:
+            continue
+        if k == "color":
+            keys.append(["%scolor: %s" % (ind, _fz_tuple(rng))])
+        elif k == "pattern":
+            ty = ["stripes", "rings", "checkers", "gradient", "uniform", "plain", "plaid"][int(rng.integers(0, 7))]
+            p = ["%spattern:" % ind, "%s  type: %s" % (ind, ty)]
+            if ty in ("uniform", "plain"):
+                p.append("%s  color: %s" % (ind, _fz_tuple(rng)))
+            else:
+                p += ["%s  color1: %s" % (ind, _fz_tuple(rng)), "%s  color2: %s" % (ind, _fz_tuple(rng))]
+            if rng.random() < 0.6:
+                p += ["%s  transform:" % ind] + _fz_transform(rng, ind + "    ")
+            keys.append(p)
+        elif k == "extends":
+            if names:
+                keys.append(["%sextends: %s" % (ind, names[int(rng.integers(0, len(names)))])])
+        elif k == "colour":
+            keys.append(["%scolour: red" % ind])                     # unknown key: warning only
+        else:
+            keys.append(["%s%s: %s" % (ind, k, _fz_num(rng))])
+    return keys
+
+
+def _fz_shape(rng, ind, mats, groups, operand):
+    kind = ["sphere", "cube", "plane"][int(rng.integers(0, 3))]
+    lines = ["add: " + kind]
+    for k in rng.permutation(["material", "transform", "group", "shadow"]):
+        if k == "material" and mats and rng.random() < 0.7:
+            lines.append("material: " + (mats[int(rng.integers(0, len(mats)))] if rng.random() > 0.02 else "nope"))
+        elif k == "transform" and rng.random() < 0.7:
+            lines += ["transform:"] + _fz_transform(rng, "  ")
+        elif k == "group" and groups and not operand and rng.random() < 0.5:
+            lines.append("group: " + (groups[int(rng.integers(0, len(groups)))] if rng.random() > 0.02 else "nope"))
+        elif k == "shadow" and rng.random() < 0.1:
+            lines.append("shadow: false")
+    return [ind + l for l in lines]
+
+
+def _fz_csg(rng, ind, mats, depth):
+    lines = ["add: csg"]
+    for k in rng.permutation(["operator", "transform", "operands"]):
+        if k == "operator":
+            lines.append("operator: " + ["union", "intersection", "difference"][int(rng.integers(0, 3))])
+        elif k == "transform" and rng.random() < 0.5:
+            lines += ["transform:"] + _fz_transform(rng, "  ")
+        elif k == "operands":
+            lines.append("operands:")
+            for _ in range(2):
+                sub = (_fz_csg(rng, "", mats, depth + 1) if depth < 2 and rng.random() < 0.3
+                       else _fz_shape(rng, "", mats, [], True))
+                lines += ["  - " + sub[0]] + ["    " + l for l in sub[1:]]
+    return [ind + l for l in lines]
+
+
+def _fz_doc(rng):
+    out, mats, groups = [], [], []
+
+    def item(lines):
+        out.append("- " + lines[0]); out.extend("  " + l for l in lines[1:])
+
+    for _ in range(int(rng.integers(3, 14))):
+        k = int(rng.integers(0, 8))
+        if k == 0:
+            cam = ["add: camera", "width: %d" % rng.integers(1, 400), "height: %d" % rng.integers(1, 300),
+                   "field-of-view: " + _fz_num(rng, ints=False)]
+            if rng.random() < 0.8:
+                cam += ["from: " + _fz_tuple(rng), "to: " + _fz_tuple(rng), "up: " + _fz_tuple(rng)]
+            item(cam)
+        elif k == 1:
+            item(["add: light", "at: " + _fz_tuple(rng), "intensity: " + _fz_tuple(rng)])
+        elif k == 2:
+            name = "m%d" % len(mats)
+            body = _fz_material_keys(rng, "", mats)
+            body.insert(int(rng.integers(0, len(body) + 1)), ["name: " + name])   # 'name' anywhere among the keys
+            item(["define: material"] + [l for k in body for l in k])
+            mats.append(name)
+        elif k == 3:
+            name = "g%d" % len(groups)
+            g = ["define: group", "name: " + name]
+            if groups and rng.random() < 0.6:
+                g.append("parent: " + groups[int(rng.integers(0, len(groups)))])
+            if rng.random() < 0.7:
+                g += ["transform:"] + _fz_transform(rng, "  ")
+            item(g); groups.append(name)
+        elif k == 4:
+            item(_fz_csg(rng, "", mats, 0))
+        elif k == 5 and rng.random() < 0.3:
+            item(["add: teapot", "size: 3"])                          # unknown 'add': warning only
+        else:
+            item(_fz_shape(rng, "", mats, groups, False))
+        if rng.random() < 0.15:
+            out.append("# comment %d" % len(out))
+    return "\n".join(out) + "\n"
+
+
+def test_yaml_loader_fuzz_against_python_loader():
+    """N2: the C++ loader and the independent PyYAML-based restatement must issue the same builder calls
+    (serialised world + cameras byte-identical) on generated scene files; both must reject the same files."""
+    rng = np.random.default_rng(20261111)
+    n_ok = n_cam = 0
+    for i in range(300):
+        text = _fz_doc(rng)
+        try:
+            w2, c2 = yaml_scene.load(text, rtx.API)
+        except (yaml_scene.SceneError, KeyError):
+            with pytest.raises(rtx.RtxError):
+                rtx.load_yaml(text)
+            continue
+        w1, c1 = rtx.load_yaml(text)
+        assert rtx.serialize(w1) == rtx.serialize(w2), "doc %d:\n%s" % (i, text)
+        assert len(c1) == len(c2), text
+        for a, b in zip(c1, c2):
+            # NaN fields (e.g. a degenerate view transform) compare as bytes too: same operations, same NaNs
+            assert _same(np.frombuffer(bytes(a), np.float64, offset=8), np.frombuffer(bytes(b), np.float64, offset=8)), text
+            assert bytes(a)[:8] == bytes(b)[:8]
+        n_ok += 1; n_cam += len(c1)
+    assert 240 < n_ok < 300 and n_cam > 50
