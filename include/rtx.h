@@ -151,6 +151,16 @@ int  rtx_render(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rt
 int  rtx_render_device(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
                        uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats);
 
+/* SURVEY.md §8f N4 — several frames of ONE resident scene: all cameras of a scene file (yaml.rs:34 parses
+ * every `add: camera`, main.rs:24 renders only cameras[0]) or an animation sweep.  Every frame's launches are
+ * queued back to back on the context's stream, the host waits once, then copies each image out: no per-frame
+ * synchronisation, allocation or upload.  Frames may differ in size.  rgb: n_cams host pointers
+ * (hsize*vsize*3 bytes each); hit: NULL or n_cams pointers, each NULL or hsize*vsize int32; stats: NULL or
+ * n_cams records (kernel_ms is each frame's own launches).  Each frame equals what rtx_render returns for
+ * that camera.  Multi-GPU use is frame-parallel: rank r renders cameras r, r+N, ... (no collective). */
+int  rtx_render_batch(rtx_ctx*, const rtx_scene*, const rtx_camera* cams, int n_cams, int max_depth,
+                      uint32_t flags, uint8_t* const* rgb, int32_t* const* hit, rtx_stats* stats);
+
 /* rows (padded to whole bands) a rank holds under `bands`, i.e. the compact buffer height */
 int  rtx_band_rows(int vsize, rtx_bands bands);
 

@@ -96,6 +96,9 @@ const char* rtxh_last_error(void);
 int  rtxh_write_png(const char* path, const uint8_t* rgb, int width, int height);
 /* main.rs:20-28: load scene file, render cameras[0] on `device`, write <stem>.png into out_dir */
 int  rtxh_render_file(const char* yaml_path, const char* out_dir, int device);
+/* N4: the same for EVERY camera of the file through rtx_render_batch (scene uploaded once): cameras[0] ->
+ * <stem>.png as above, cameras[i>0] -> <stem>.cam<i>.png.  n_rendered_out (may be NULL) = images written. */
+int  rtxh_render_file_all(const char* yaml_path, const char* out_dir, int device, int* n_rendered_out);
 
 #ifdef __cplusplus
 }

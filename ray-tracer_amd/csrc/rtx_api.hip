@@ -44,9 +44,15 @@ struct rtx_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_counters = nullptr;
-    int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0;   // tile class lists (grown on demand)
+    // scheduling state of one stream: tile class lists (grown on demand) and their fill counts.  lanes[0] runs
+    // on `stream`; lanes 1.. have streams of their own and are created by the first rtx_render_batch
+    struct Lane { hipStream_t stream = nullptr; int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0; };
+    static constexpr int kLanes = 4;
+    Lane lanes[kLanes];
+    uint8_t* h_stage = nullptr; size_t stage_cap = 0;                        // pinned staging of a batch's images
     uint8_t* d_rgb = nullptr; size_t rgb_cap = 0;
     int32_t* d_hit = nullptr; size_t hit_cap = 0;
+    unsigned long long* d_batch_counters = nullptr; size_t batch_cap = 0;   // one counter block per frame of a batch
     std::string err;
 };
 
@@ -371,10 +377,11 @@ int rtx_init(int device, rtx_ctx** out) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void**)&c->d_tile_counts, 64 * sizeof(int32_t)) != hipSuccess) {
+        hipMalloc((void**)&c->lanes[0].d_tile_counts, 64 * sizeof(int32_t)) != hipSuccess) {
         delete c;
         return RTX_E_DEVICE;
     }
+    c->lanes[0].stream = c->stream;
     *out = c;
     return RTX_OK;
 }
@@ -385,8 +392,13 @@ void rtx_shutdown(rtx_ctx* c) {
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->d_lists) (void)hipFree(c->d_lists);
-    if (c->d_tile_counts) (void)hipFree(c->d_tile_counts);
+    if (c->d_batch_counters) (void)hipFree(c->d_batch_counters);
+    for (int l = 0; l < rtx_ctx::kLanes; l++) {
+        if (c->lanes[l].d_lists) (void)hipFree(c->lanes[l].d_lists);
+        if (c->lanes[l].d_tile_counts) (void)hipFree(c->lanes[l].d_tile_counts);
+        if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
+    }
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -538,8 +550,16 @@ int rtx_band_rows(int vsize, rtx_bands b) {
     return local_bands(vsize, b) * RTX_TILE;
 }
 
-int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
-                      uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats) {
+}  // extern "C"
+
+namespace {
+
+constexpr size_t kCounterWords = (size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE;
+
+// Queues one render (counter reset, optional tile-order probe, frame launch) on `st`; nothing here waits.
+int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+                   uint32_t flags, void* d_rgb, void* d_hit, hipStream_t st, rtx_ctx::Lane* lane,
+                   unsigned long long* d_counters, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (!ctx || !scene || !cam || !d_rgb) return RTX_E_INVALID;
     if (scene->ctx != ctx) return fail(ctx, RTX_E_INVALID, "scene belongs to another context");
     if (cam->hsize <= 0 || cam->vsize <= 0) return fail(ctx, RTX_E_INVALID, "empty camera");
@@ -576,9 +596,8 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
     rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long), st));
-    if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+    HIPCHK(ctx, hipMemsetAsync(d_counters, 0, kCounterWords * sizeof(unsigned long long), st));
+    if (ev_begin) HIPCHK(ctx, hipEventRecord(ev_begin, st));
     // ---- expensive tiles first: a probe launch (the centre pixel of every tile, depth budget 2, no image, no
     // counters) files every tile under a cost class; the frame launch walks the classes most expensive first.
     // A wave runs until its slowest pixel is done (up to ~126 rays for a glass pixel at depth 5); in an arbitrary
@@ -590,13 +609,13 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
         const char* e = getenv("RTX_LPT");
         const bool want = e ? atoi(e) != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching);
         if (want && n_tiles > 0) {
-            if (ctx->tile_cap < (size_t)n_tiles) {
-                if (ctx->d_lists) (void)hipFree(ctx->d_lists);
-                ctx->d_lists = nullptr; ctx->tile_cap = 0;
-                HIPCHK(ctx, hipMalloc((void**)&ctx->d_lists, (size_t)RTX_TILE_CLASSES * n_tiles * sizeof(int32_t)));
-                ctx->tile_cap = n_tiles;
+            if (lane->tile_cap < (size_t)n_tiles) {
+                if (lane->d_lists) (void)hipFree(lane->d_lists);
+                lane->d_lists = nullptr; lane->tile_cap = 0;
+                HIPCHK(ctx, hipMalloc((void**)&lane->d_lists, (size_t)RTX_TILE_CLASSES * n_tiles * sizeof(int32_t)));
+                lane->tile_cap = n_tiles;
             }
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_counts, 0, RTX_TILE_CLASSES * sizeof(int32_t), st));
+            HIPCHK(ctx, hipMemsetAsync(lane->d_tile_counts, 0, RTX_TILE_CLASSES * sizeof(int32_t), st));
             RenderParams pp = rp;
             {
                 const long long n_super = (long long)((rp.tiles_x + 7) / 8) * ((rp.n_bands_local + 7) / 8);
@@ -607,40 +626,58 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
                 if (pp.super_mul == 0) pp.super_mul = 1;
             }
             pp.probe = 1; pp.max_depth = getenv("RTX_PROBE_DEPTH") ? atoi(getenv("RTX_PROBE_DEPTH")) : 2;   // (1, 2, 3 measured: 2 is best)
-            if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = ctx->d_lists; pp.tile_counts = ctx->d_tile_counts;
-            HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, ctx->d_counters, 0, st));
-            rp.use_lists = 1; rp.tile_lists = ctx->d_lists; rp.tile_counts = ctx->d_tile_counts;
+            if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lane->d_lists; pp.tile_counts = lane->d_tile_counts;
+            HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, st));
+            rp.use_lists = 1; rp.tile_lists = lane->d_lists; rp.tile_counts = lane->d_tile_counts;
         }
     }
-    HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &rp, (uint8_t*)d_rgb, (int32_t*)d_hit, ctx->d_counters,
+    HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &rp, (uint8_t*)d_rgb, (int32_t*)d_hit, d_counters,
                                        (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, st));
-    if (stats) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev1, st));
-        std::vector<unsigned long long> rep((size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE);
-        HIPCHK(ctx, hipMemcpyAsync(rep.data(), ctx->d_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        unsigned long long h[RTX_CNT_TOTAL] = {0};
-        for (int sl = 0; sl < RTX_CNT_SLOTS; sl++)
-            for (int k = 0; k < RTX_CNT_TOTAL; k++) h[k] += rep[(size_t)sl * RTX_CNT_STRIDE + k];
-        float ms = 0.f;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        std::memset(stats, 0, sizeof *stats);
-        // valid pixels of the rendered bands = primary rays
-        uint64_t prim = 0;
-        for (int b = 0; b < rp.n_bands_local; b++) {
-            int y0 = (bands.first + b * bands.stride) * RTX_TILE;
-            int rows = cam->vsize - y0; if (rows > RTX_TILE) rows = RTX_TILE;
-            if (rows > 0) prim += (uint64_t)rows * cam->hsize;
-        }
-        stats->rays_primary = prim;
-        stats->rays_secondary = h[RTX_CNT_RADIANCE] - prim;
-        stats->rays_shadow = h[RTX_CNT_SHADOW];
-        stats->overflow_pixels = h[RTX_CNT_OVERFLOW];
-        for (int i = 0; i < RTX_EV_COUNT; i++) stats->ev[i] = h[RTX_CNT_EV0 + i];
-        stats->kernel_ms = ms;
-        if (stats->overflow_pixels) return fail(ctx, RTX_E_CAPACITY, "bounded CSG list overflowed on the device");
-    }
+    if (ev_end) HIPCHK(ctx, hipEventRecord(ev_end, st));
     return RTX_OK;
+}
+
+// Sums the replicated counter block `rep` (already on the host) into *stats.
+int fill_stats(rtx_ctx* ctx, const rtx_camera* cam, rtx_bands bands, const unsigned long long* rep, float ms, rtx_stats* stats) {
+    unsigned long long h[RTX_CNT_TOTAL] = {0};
+    for (int sl = 0; sl < RTX_CNT_SLOTS; sl++)
+        for (int k = 0; k < RTX_CNT_TOTAL; k++) h[k] += rep[(size_t)sl * RTX_CNT_STRIDE + k];
+    std::memset(stats, 0, sizeof *stats);
+    // valid pixels of the rendered bands = primary rays
+    uint64_t prim = 0;
+    const int nb = local_bands(cam->vsize, bands);
+    for (int b = 0; b < nb; b++) {
+        int y0 = (bands.first + b * bands.stride) * RTX_TILE;
+        int rows = cam->vsize - y0; if (rows > RTX_TILE) rows = RTX_TILE;
+        if (rows > 0) prim += (uint64_t)rows * cam->hsize;
+    }
+    stats->rays_primary = prim;
+    stats->rays_secondary = h[RTX_CNT_RADIANCE] - prim;
+    stats->rays_shadow = h[RTX_CNT_SHADOW];
+    stats->overflow_pixels = h[RTX_CNT_OVERFLOW];
+    for (int i = 0; i < RTX_EV_COUNT; i++) stats->ev[i] = h[RTX_CNT_EV0 + i];
+    stats->kernel_ms = ms;
+    if (stats->overflow_pixels) return fail(ctx, RTX_E_CAPACITY, "bounded CSG list overflowed on the device");
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+                      uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats) {
+    if (!ctx) return RTX_E_INVALID;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = enqueue_render(ctx, scene, cam, max_depth, bands, flags, d_rgb, d_hit, st, &ctx->lanes[0], ctx->d_counters,
+                            stats ? ctx->ev0 : nullptr, stats ? ctx->ev1 : nullptr);
+    if (rc != RTX_OK || !stats) return rc;
+    std::vector<unsigned long long> rep(kCounterWords);
+    HIPCHK(ctx, hipMemcpyAsync(rep.data(), ctx->d_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    return fill_stats(ctx, cam, bands, rep.data(), ms, stats);
 }
 
 int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
@@ -693,6 +730,105 @@ int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int 
         }
     }
     return RTX_OK;
+}
+
+int rtx_render_batch(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cams, int n_cams, int max_depth,
+                     uint32_t flags, uint8_t* const* rgb, int32_t* const* hit, rtx_stats* stats) {
+    if (!ctx || !scene || !cams || !rgb || n_cams < 0) return RTX_E_INVALID;
+    if (flags & RTX_F_BANDS_COMPACT) return fail(ctx, RTX_E_INVALID, "a batch renders whole frames");
+    if (n_cams == 0) return RTX_OK;
+    // one device image per frame, carved out of the context's (grown on demand) output buffers
+    std::vector<size_t> off_rgb(n_cams + 1, 0), off_hit(n_cams + 1, 0);
+    for (int i = 0; i < n_cams; i++) {
+        if (cams[i].hsize <= 0 || cams[i].vsize <= 0 || !rgb[i]) return fail(ctx, RTX_E_INVALID, "empty camera or NULL image in batch");
+        const size_t rows = (size_t)rtx_band_rows(cams[i].vsize, rtx_bands{0, 1});      // padded to whole tiles
+        const size_t npx = rows * cams[i].hsize;
+        off_rgb[i + 1] = off_rgb[i] + ((npx * 3 + 255) & ~(size_t)255);
+        off_hit[i + 1] = off_hit[i] + ((hit && hit[i]) ? ((npx * 4 + 255) & ~(size_t)255) : 0);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (off_rgb[n_cams] > ctx->rgb_cap) {
+        if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+        ctx->d_rgb = nullptr; ctx->rgb_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_rgb, off_rgb[n_cams]));
+        ctx->rgb_cap = off_rgb[n_cams];
+    }
+    if (off_hit[n_cams] > ctx->hit_cap) {
+        if (ctx->d_hit) (void)hipFree(ctx->d_hit);
+        ctx->d_hit = nullptr; ctx->hit_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_hit, off_hit[n_cams]));
+        ctx->hit_cap = off_hit[n_cams];
+    }
+    if ((size_t)n_cams > ctx->batch_cap) {
+        if (ctx->d_batch_counters) (void)hipFree(ctx->d_batch_counters);
+        ctx->d_batch_counters = nullptr; ctx->batch_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_batch_counters, (size_t)n_cams * kCounterWords * sizeof(unsigned long long)));
+        ctx->batch_cap = n_cams;
+    }
+    // frames go round-robin over kLanes streams, so small frames overlap and fill the chip together; each
+    // frame's image is copied to pinned staging on its own stream (the copy overlaps the other lanes' kernels)
+    const int n_lanes = n_cams < rtx_ctx::kLanes ? n_cams : rtx_ctx::kLanes;
+    size_t max_tiles = 0;
+    for (int i = 0; i < n_cams; i++) {
+        const size_t t = (size_t)((cams[i].hsize + RTX_TILE - 1) / RTX_TILE) * ((cams[i].vsize + RTX_TILE - 1) / RTX_TILE);
+        if (t > max_tiles) max_tiles = t;
+    }
+    for (int l = 0; l < n_lanes; l++) {
+        rtx_ctx::Lane& ln = ctx->lanes[l];
+        if (!ln.stream) HIPCHK(ctx, hipStreamCreate(&ln.stream));
+        if (!ln.d_tile_counts) HIPCHK(ctx, hipMalloc((void**)&ln.d_tile_counts, 64 * sizeof(int32_t)));
+        if (scene->dev.has_branching && ln.tile_cap < max_tiles) {           // grow now: hipFree would stall the queue later
+            if (ln.d_lists) (void)hipFree(ln.d_lists);
+            ln.d_lists = nullptr; ln.tile_cap = 0;
+            HIPCHK(ctx, hipMalloc((void**)&ln.d_lists, (size_t)RTX_TILE_CLASSES * max_tiles * sizeof(int32_t)));
+            ln.tile_cap = max_tiles;
+        }
+    }
+    const size_t stage_bytes = off_rgb[n_cams] + off_hit[n_cams];
+    if (stage_bytes > ctx->stage_cap) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr; ctx->stage_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage, stage_bytes, hipHostMallocDefault));
+        ctx->stage_cap = stage_bytes;
+    }
+    std::vector<hipEvent_t> ev(stats ? (size_t)n_cams * 2 : 0, nullptr);
+    auto drop_events = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (hipEvent_t& e : ev) if (hipEventCreate(&e) != hipSuccess) { drop_events(); return fail(ctx, RTX_E_DEVICE, "hipEventCreate failed"); }
+    int rc = RTX_OK;
+    for (int i = 0; i < n_cams && rc == RTX_OK; i++) {
+        rtx_ctx::Lane& ln = ctx->lanes[i % n_lanes];
+        const size_t npx = (size_t)cams[i].hsize * cams[i].vsize;
+        const bool want_hit = hit && hit[i];
+        rc = enqueue_render(ctx, scene, &cams[i], max_depth, rtx_bands{0, 1}, flags, ctx->d_rgb + off_rgb[i],
+                            want_hit ? (void*)((uint8_t*)ctx->d_hit + off_hit[i]) : nullptr, ln.stream, &ln,
+                            ctx->d_batch_counters + (size_t)i * kCounterWords,
+                            stats ? ev[2 * i] : nullptr, stats ? ev[2 * i + 1] : nullptr);
+        if (rc != RTX_OK) break;
+        if (hipMemcpyAsync(ctx->h_stage + off_rgb[i], ctx->d_rgb + off_rgb[i], npx * 3, hipMemcpyDeviceToHost, ln.stream) != hipSuccess ||
+            (want_hit && hipMemcpyAsync(ctx->h_stage + off_rgb[n_cams] + off_hit[i], (uint8_t*)ctx->d_hit + off_hit[i], npx * 4,
+                                        hipMemcpyDeviceToHost, ln.stream) != hipSuccess))
+            rc = fail(ctx, RTX_E_DEVICE, "device to host copy failed");
+    }
+    // every lane is drained even after an error: nothing of this call may still be running when it returns
+    for (int l = 0; l < n_lanes; l++)
+        if (hipStreamSynchronize(ctx->lanes[l].stream) != hipSuccess && rc == RTX_OK) rc = fail(ctx, RTX_E_DEVICE, "hipStreamSynchronize failed");
+    for (int i = 0; i < n_cams && rc == RTX_OK; i++) {
+        const size_t npx = (size_t)cams[i].hsize * cams[i].vsize;
+        std::memcpy(rgb[i], ctx->h_stage + off_rgb[i], npx * 3);
+        if (hit && hit[i]) std::memcpy(hit[i], ctx->h_stage + off_rgb[n_cams] + off_hit[i], npx * 4);
+    }
+    if (rc == RTX_OK && stats) {
+        std::vector<unsigned long long> rep((size_t)n_cams * kCounterWords);
+        if (hipMemcpy(rep.data(), ctx->d_batch_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, RTX_E_DEVICE, "counter copy failed");
+        for (int i = 0; i < n_cams && rc == RTX_OK; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { rc = fail(ctx, RTX_E_DEVICE, "hipEventElapsedTime failed"); break; }
+            rc = fill_stats(ctx, &cams[i], rtx_bands{0, 1}, rep.data() + (size_t)i * kCounterWords, ms, &stats[i]);
+        }
+    }
+    drop_events();
+    return rc;
 }
 
 }  // extern "C"

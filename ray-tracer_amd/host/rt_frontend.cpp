@@ -59,4 +59,52 @@ int rtxh_render_file(const char* yaml_path, const char* out_dir, int device) {
     return rtxh_write_png(out.c_str(), rgb.data(), cam.hsize, cam.vsize);
 }
 
+int rtxh_render_file_all(const char* yaml_path, const char* out_dir, int device, int* n_rendered_out) {
+    if (n_rendered_out) *n_rendered_out = 0;
+    if (!yaml_path) return RTX_E_INVALID;
+    std::ifstream in(yaml_path, std::ios::binary);
+    if (!in) { g_err = std::string("cannot read ") + yaml_path; return RTX_E_INVALID; }
+    std::stringstream ss; ss << in.rdbuf();
+    const std::string text = ss.str();
+    rtxh_world* w = nullptr; int ncam = 0;
+    std::vector<rtxh_camera> cams(64);                                       // one parse (warnings print once)
+    int rc = rtxh_load_yaml(text.c_str(), &w, cams.data(), (int)cams.size(), &ncam);
+    if (rc != RTX_OK) return rc;
+    if (ncam < 1) { g_err = "scene has no camera"; rtxh_world_free(w); return RTX_E_INVALID; }
+    if (ncam > (int)cams.size()) { g_err = "more than 64 cameras"; rtxh_world_free(w); return RTX_E_CAPACITY; }
+    cams.resize(ncam);
+    rtx_ctx* ctx = nullptr; rtx_scene* scene = nullptr;
+    rc = rtx_init(device, &ctx);
+    if (rc != RTX_OK) { g_err = "rtx_init failed: no usable HIP device"; rtxh_world_free(w); return rc; }
+    rc = rtxh_scene_create(ctx, w, &scene);
+    std::vector<rtx_camera> flat(ncam);
+    std::vector<std::vector<uint8_t>> images(ncam);
+    std::vector<uint8_t*> ptrs(ncam);
+    for (int i = 0; i < ncam && rc == RTX_OK; i++) {
+        if (cams[i].hsize <= 0 || cams[i].vsize <= 0) { g_err = "empty camera"; rc = RTX_E_INVALID; break; }
+        rtxh_camera_flatten(&cams[i], &flat[i]);
+        images[i].resize((size_t)cams[i].hsize * cams[i].vsize * 3);
+        ptrs[i] = images[i].data();
+    }
+    if (rc == RTX_OK) rc = rtx_render_batch(ctx, scene, flat.data(), ncam, 5 /* camera.rs:42 */, 0, ptrs.data(), nullptr, nullptr);
+    if (rc != RTX_OK && g_err.empty()) g_err = rtx_last_error(ctx);
+    else if (rc != RTX_OK && ctx && *rtx_last_error(ctx)) g_err = rtx_last_error(ctx);
+    if (scene) rtx_scene_destroy(scene);
+    rtx_shutdown(ctx); rtxh_world_free(w);
+    if (rc != RTX_OK) return rc;
+    std::string p(yaml_path);
+    size_t sl = p.find_last_of('/');
+    std::string name = sl == std::string::npos ? p : p.substr(sl + 1);
+    size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) name = name.substr(0, dot);
+    const std::string stem = (out_dir && *out_dir) ? std::string(out_dir) + "/" + name : name;
+    for (int i = 0; i < ncam; i++) {
+        const std::string out = i == 0 ? stem + ".png" : stem + ".cam" + std::to_string(i) + ".png";
+        rc = rtxh_write_png(out.c_str(), images[i].data(), cams[i].hsize, cams[i].vsize);
+        if (rc != RTX_OK) return rc;
+        if (n_rendered_out) ++*n_rendered_out;
+    }
+    return RTX_OK;
+}
+
 }  // extern "C"

@@ -67,7 +67,7 @@ class SceneDesc(C.Structure):
 
 # every symbol include/rtx.h and include/rtx_host.h declare
 RTX_SYMBOLS = ["rtx_init", "rtx_shutdown", "rtx_scene_create", "rtx_scene_destroy", "rtx_render",
-               "rtx_render_device", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
+               "rtx_render_device", "rtx_render_batch", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
 RTXH_SYMBOLS = ["rtxh_identity", "rtxh_translation", "rtxh_scaling", "rtxh_rotation_x", "rtxh_rotation_y",
                 "rtxh_rotation_z", "rtxh_view_transform", "rtxh_mat_mul", "rtxh_inverse",
                 "rtxh_default_material", "rtxh_world_new", "rtxh_world_free", "rtxh_add_shape",
@@ -75,7 +75,7 @@ RTXH_SYMBOLS = ["rtxh_identity", "rtxh_translation", "rtxh_scaling", "rtxh_rotat
                 "rtxh_add_light", "rtxh_build", "rtxh_set_material_of", "rtxh_get_material_of",
                 "rtxh_set_light", "rtxh_get_bounds", "rtxh_camera_new", "rtxh_world_serialize", "rtxh_scene_create",
                 "rtxh_camera_flatten", "rtxh_render", "rtxh_load_yaml", "rtxh_last_error",
-                "rtxh_write_png", "rtxh_render_file"]
+                "rtxh_write_png", "rtxh_render_file", "rtxh_render_file_all"]
 
 
 def _load():
@@ -91,6 +91,7 @@ def _load():
         "rtx_scene_destroy": (None, [vp]),
         "rtx_render": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, pu8, pi32, C.POINTER(Stats)]),
         "rtx_render_device": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, vp, vp, vp, C.POINTER(Stats)]),
+        "rtx_render_batch": (i, [vp, vp, C.POINTER(RtxCamera), i, i, u32, C.POINTER(pu8), C.POINTER(pi32), C.POINTER(Stats)]),
         "rtx_band_rows": (i, [i, Bands]),
         "rtx_debug_math": (i, [vp, i, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rtx_strerror": (C.c_char_p, [i]), "rtx_last_error": (C.c_char_p, [vp]),
@@ -102,6 +103,7 @@ def _load():
         "rtxh_last_error": (C.c_char_p, []),
         "rtxh_write_png": (i, [C.c_char_p, pu8, i, i]),
         "rtxh_render_file": (i, [C.c_char_p, C.c_char_p, i]),
+        "rtxh_render_file_all": (i, [C.c_char_p, C.c_char_p, i, C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -203,6 +205,19 @@ class Scene:
                             hit.ctypes.data_as(C.POINTER(C.c_int32)) if hit is not None else None, C.byref(st))
         self.ctx._check(rc)
         return dict(rgb=rgb, hit=hit, stats=st)
+
+    def render_batch(self, cams, max_depth=5, flags=0, want_hit=True, want_stats=True):
+        """rtx_render_batch: every camera against the resident scene, one wait for all frames."""
+        n = len(cams)
+        flat = (RtxCamera * n)(*[self.flat_camera(c) for c in cams])
+        rgb = [np.zeros((c.vsize, c.hsize, 3), np.uint8) for c in cams]
+        hit = [np.full((c.vsize, c.hsize), -2, np.int32) for c in cams] if want_hit else None
+        pu8, pi32 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+        prgb = (pu8 * n)(*[a.ctypes.data_as(pu8) for a in rgb])
+        phit = (pi32 * n)(*[a.ctypes.data_as(pi32) for a in hit]) if want_hit else None
+        st = (Stats * n)() if want_stats else None
+        self.ctx._check(LIB.rtx_render_batch(self.ctx.h, self.h, flat, n, max_depth, flags, prgb, phit, st))
+        return [dict(rgb=rgb[k], hit=hit[k] if want_hit else None, stats=st[k] if want_stats else None) for k in range(n)]
 
     def render_device(self, cam, d_rgb, d_hit=0, max_depth=5, bands=(0, 1), flags=0, stream=0, stats=False):
         """rtx_render_device: outputs are device pointers (ints), e.g. torch tensor .data_ptr()."""

@@ -212,3 +212,62 @@ def test_tile_order_does_not_change_the_image(ctx, monkeypatch):
         assert np.array_equal(rgb, a["rgb"]) and np.array_equal(hit, a["hit"])
     finally:
         sc.close()
+
+
+def _with_extra_cameras(text, extra):
+    return text + "".join("- add: camera\n  width: %d\n  height: %d\n  field-of-view: %s\n  from: %s\n  to: %s\n  up: [0, 1, 0]\n" % c
+                          for c in extra)
+
+
+def test_batch_of_cameras_equals_single_renders(ctx, monkeypatch):
+    """SURVEY.md §8f N4 (rtx_render_batch): every `add: camera` of a file (yaml.rs:34; the reference renders
+    only cameras[0], main.rs:24) against ONE resident scene, queued back to back with one wait.  Each frame
+    (different sizes, ragged, one large enough for the tile-order probe) must be byte-identical to
+    rtx_render's, with its own ray and event counts; cameras[0] is additionally checked against the oracle."""
+    import ora
+    import rtapi
+    import rtx
+    text = _with_extra_cameras(parity.scene_text("S4", 160, 96),
+                               [(101, 53, "pi / 3", "[3, 2, -9]", "[0, 1, 0]"), (512, 320, "0.9", "[-4, 5, -10]", "[0, 0.5, 0]"),
+                                (8, 8, "pi / 2", "[0, 1, -5]", "[0, 1, 0]")])
+    pw, pcs = rtx.load_yaml(text)
+    assert len(pcs) == 4
+    sc = ctx.scene(pw)
+    try:
+        monkeypatch.setenv("RTX_LPT", "1")                       # the probe and its lists are shared by the queued frames
+        batch = sc.render_batch(pcs, 5, flags=rtx.F_COUNT_EVENTS)
+        for k, cam in enumerate(pcs):
+            one = sc.render(cam, 5, flags=rtx.F_COUNT_EVENTS)
+            assert np.array_equal(batch[k]["rgb"], one["rgb"]) and np.array_equal(batch[k]["hit"], one["hit"]), k
+            bs, os_ = batch[k]["stats"], one["stats"]
+            assert (bs.rays_primary, bs.rays_shadow, bs.rays_secondary) == (os_.rays_primary, os_.rays_shadow, os_.rays_secondary)
+            assert bs.events() == os_.events() and bs.kernel_ms > 0
+        monkeypatch.delenv("RTX_LPT")
+        plain = sc.render_batch(pcs, 5, want_hit=False, want_stats=False)
+        assert all(np.array_equal(plain[k]["rgb"], batch[k]["rgb"]) for k in range(4))
+        assert sc.render_batch([], 5) == []
+        with pytest.raises(rtx.RtxError):
+            sc.render_batch(pcs, 5, flags=rtx.F_BANDS_COMPACT)
+    finally:
+        sc.close()
+    (_, _), (ow, oc) = parity.build_both(parity.scene_text("S4", 160, 96))
+    cpu = ora.render(ow, oc, 5, threads=8)
+    parity.assert_parity(batch[0], cpu, "batch frame 0")
+    assert batch[0]["stats"].rays == cpu["stats"].rays
+
+
+def test_cli_all_cameras(ctx, tmp_path):
+    """`rtx <scene> --all-cameras`: cameras[0] -> <stem>.png exactly as main.rs:25-26, the others -> <stem>.cam<i>.png."""
+    import os
+    import subprocess
+    from PIL import Image
+    import rtx
+    text = _with_extra_cameras(parity.scene_text("S1", 96, 48), [(40, 30, "pi / 2", "[0, 3, -6]", "[0, 1, 0]")])
+    scene = tmp_path / "two.yaml"
+    scene.write_text(text)
+    exe = os.path.join(os.path.dirname(rtx.LIB_PATH), "rtx")
+    subprocess.run([exe, str(scene), "--all-cameras"], check=True, timeout=100, cwd=str(tmp_path))
+    pw, pcs = rtx.load_yaml(text)
+    for k, name in enumerate(["two.png", "two.cam1.png"]):
+        img = np.asarray(Image.open(str(tmp_path / name)))
+        assert np.array_equal(img, ctx.render(pw, pcs[k], 5)["rgb"]), name
