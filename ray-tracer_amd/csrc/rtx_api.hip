@@ -46,7 +46,9 @@ struct rtx_ctx {
     unsigned long long* d_counters = nullptr;
     // scheduling state of one stream: tile class lists (grown on demand) and their fill counts.  lanes[0] runs
     // on `stream`; lanes 1.. have streams of their own and are created by the first rtx_render_batch
-    struct Lane { hipStream_t stream = nullptr; int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0; };
+    // side/ev_fork/ev_join: the SPLIT launch of a frame runs on `side`, beside the main launch (created on first use)
+    struct Lane { hipStream_t stream = nullptr; int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0;
+                  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
     static constexpr int kLanes = 4;
     Lane lanes[kLanes];
     uint8_t* h_stage = nullptr; size_t stage_cap = 0;                        // pinned staging of a batch's images
@@ -397,6 +399,9 @@ void rtx_shutdown(rtx_ctx* c) {
         if (c->lanes[l].d_lists) (void)hipFree(c->lanes[l].d_lists);
         if (c->lanes[l].d_tile_counts) (void)hipFree(c->lanes[l].d_tile_counts);
         if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
+        if (c->lanes[l].side) (void)hipStreamDestroy(c->lanes[l].side);
+        if (c->lanes[l].ev_fork) (void)hipEventDestroy(c->lanes[l].ev_fork);
+        if (c->lanes[l].ev_join) (void)hipEventDestroy(c->lanes[l].ev_join);
     }
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -629,10 +634,36 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lane->d_lists; pp.tile_counts = lane->d_tile_counts;
             HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, st));
             rp.use_lists = 1; rp.tile_lists = lane->d_lists; rp.tile_counts = lane->d_tile_counts;
+            // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
+            // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
+            // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
+            const char* se = getenv("RTX_SPLIT");
+            const bool split = se ? atoi(se) != 0 : n_tiles <= RTX_SPLIT_MAX_TILES;
+            if (split) {
+                rp.split_cap = n_tiles / 4 > 0 ? n_tiles / 4 : 1;
+                rp.split_min_class = getenv("RTX_SPLIT_CLASS") ? atoi(getenv("RTX_SPLIT_CLASS")) : 6;
+                if (rp.split_min_class < 1) rp.split_min_class = 1;
+            }
         }
+    }
+    if (rp.split_cap > 0) {
+        // fork: the SPLIT launch (expensive tiles, several waves each) goes first, on the lane's side stream; the
+        // main launch renders the other tiles beside it and waits for it at the end
+        if (!lane->side) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&lane->side, hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_fork, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventRecord(lane->ev_fork, st));
+        HIPCHK(ctx, hipStreamWaitEvent(lane->side, lane->ev_fork, 0));
+        RenderParams sp = rp; sp.split_launch = 1;
+        HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &sp, (uint8_t*)d_rgb, (int32_t*)d_hit, d_counters,
+                                           (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, lane->side));
+        HIPCHK(ctx, hipEventRecord(lane->ev_join, lane->side));
     }
     HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &rp, (uint8_t*)d_rgb, (int32_t*)d_hit, d_counters,
                                        (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, st));
+    if (rp.split_cap > 0) HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_join, 0));
     if (ev_end) HIPCHK(ctx, hipEventRecord(ev_end, st));
     return RTX_OK;
 }

@@ -150,8 +150,11 @@ struct RenderParams {
     // maps block b to the b-th tile of the concatenation, most expensive class first.
     int32_t* tile_lists;       // RTX_TILE_CLASSES x n_tiles tile indices (class k at [k * n_tiles ...])
     int32_t* tile_counts;      // RTX_TILE_CLASSES list lengths (one 32-byte line)
-    int32_t super_mul, pad1;   // probe launch: block b probes the 8x8 block of tiles (b * super_mul) mod n_super
+    int32_t super_mul;         // probe launch: block b probes the 8x8 block of tiles (b * super_mul) mod n_super
+    int32_t split_cap;         // > 0: up to this many tiles of the expensive classes are rendered by several waves (SPLIT kernels)
     int32_t probe, use_lists;  // probe: this IS the probe launch (no image, no counters); use_lists: follow the lists
+    int32_t split_launch;     // this IS the SPLIT launch (the expensive tiles, several waves per tile)
+    int32_t split_min_class;  // SPLIT kernels: tiles of this class and above are split (up to split_cap tiles)
     int32_t tile_mul;         // block b renders tile (b * tile_mul) mod n_tiles: coprime with n_tiles, spreads heavy image
                               //   regions over the whole dispatch instead of leaving them to the tail
 };
@@ -168,6 +171,7 @@ struct RenderParams {
 // 3.1 ms for the 129 600 waves of a 4K frame (measured; it bounded S2, S3 and S5).
 #ifndef RTX_TILE_CLASSES
 #define RTX_TILE_CLASSES 8
+#define RTX_SPLIT_MAX_TILES 20000   /* launches of at most this many tiles split their most expensive tiles over several waves */
 #endif
 #define RTX_CNT_SLOTS 256
 #define RTX_CNT_STRIDE 32

@@ -181,7 +181,10 @@ enum {
     FR_REFL = 1,         // the first child is the reflected ray (else: the only child is the refracted ray)
     FR_REFR_PENDING = 2, // a refraction ray waits in o2/d2
     FR_SECOND = 4,       // the child now being traced is that refraction ray
-    FR_BOTH = 8          // reflective > 0 && transparency > 0: Schlick mix (world.rs:142-145)
+    FR_BOTH = 8,         // reflective > 0 && transparency > 0: Schlick mix (world.rs:142-145)
+    // split tiles (SPLIT kernels): the refracted child of this hit is traced by another lane of the pixel's group
+    FR_REMOTE = 16,      // ... whose lane index is in bits 8..13; its colour arrives in that lane's mailbox
+    FR_HELPER_SHIFT = 8
 };
 
 // One op head = 8 dwords fetched with a single scalar s_load_dwordx8 (constant address space) and
@@ -259,25 +262,74 @@ const uint32_t LBIT = 0x80000000u;
 
 // PROBE: the tile-cost probe launch (rtx_api.hip) — same code, but lanes map to tile centres, nothing is written
 // to the image or the counters, and the rays needed file the tile into a cost class
-template <bool CSG, bool COUNT, bool PROBE = false>
+// SPLIT: an expensive tile is rendered by 2^RTX_SPLIT_BITS waves; each takes 64 >> RTX_SPLIT_BITS of its pixels
+// on its first lanes, the other lanes start idle.  Whenever a hit has two children (reflection AND refraction)
+// and some lane of the wave is idle — a spare lane, or one whose pixel is finished — the refracted child is
+// handed to it: its ray goes straight into the helper's LDS ray slot, the helper traces the whole subtree (handing
+// out work itself) and posts the colour color_at would have returned into its mailbox; the owner meanwhile traces
+// the reflected child and, back at the frame, takes the posted colour as if its own second trace had just returned
+// it.  Every ray is traced exactly once and every sum is evaluated by the frame's owner in the reference's order,
+// so image and counts are those of the unsplit kernel; only the wave's critical path changes: a glass pixel at
+// depth 5 is a spine of two-children hits with short side chains (up to ~110 rays one after the other), and the
+// side chains now run beside the spine.  Donors and idle lanes are paired wave-wide with two ballots per
+// iteration (k-th donor <-> k-th idle lane), no atomics.  Used for short dispatches (rtx_api.hip), where the
+// longest wave, not the throughput, bounds the frame: many GPUs per frame, small frames.
+#ifndef RTX_SPLIT_BITS
+#define RTX_SPLIT_BITS 2
+#endif
+template <bool CSG, bool COUNT, bool PROBE = false, bool SPLIT = false>
 __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
                                                          unsigned long long* __restrict__ counters_base) {
     unsigned long long* counters = counters_base;
+#ifdef RTX_WAVE_TRACE
+    // diagnostic build (tools/wave_trace.py): start / end of every wave on the 100 MHz clock go to the hit-id
+    // plane (which then holds no hit ids): [3b] start, [3b+1] end, [3b+2] rays of the slowest lane
+    const unsigned wt_start = (unsigned)__builtin_amdgcn_s_memrealtime();
+    int wt_class = 0;
+#endif
     extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
     const int lane = threadIdx.x;
     int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
+    constexpr int S = SPLIT ? RTX_SPLIT_BITS : 0;   // log2 waves per tile
+    int sub = 0;                          // which part of the tile this wave renders
     if (!PROBE && rp.use_lists) {
         // block b -> b-th tile of the class lists, most expensive class first (the probe launch filled them)
         typedef int32_t I8 __attribute__((ext_vector_type(RTX_TILE_CLASSES)));
         const I8 cnt = *(const AS4 I8*)(uintptr_t)rp.tile_counts;
         int rest = (int)blockIdx.x, k = RTX_TILE_CLASSES - 1;
+        if (rp.split_cap > 0) {
+            // the first n_split tiles of the lists (classes >= split_min_class) belong to the SPLIT launch, which runs
+            // beside this one on a second stream; both launches are sized for split_cap and drop their surplus blocks
+            int n_heavy = 0;
+#pragma unroll
+            for (int q = RTX_TILE_CLASSES - 1; q > 0; q--) n_heavy += q >= rp.split_min_class ? cnt[q] : 0;
+            const int n_split = n_heavy < rp.split_cap ? n_heavy : rp.split_cap;
+            if (SPLIT) {
+                sub = rest & ((1 << RTX_SPLIT_BITS) - 1);
+                rest >>= RTX_SPLIT_BITS;
+                if (rest >= n_split) return;
+            } else {
+                rest += n_split;
+                if (rest >= rp.tiles_x * rp.n_bands_local) return;
+            }
+        }
 #pragma unroll
         for (int q = RTX_TILE_CLASSES - 1; q > 0; q--)
             if (k == q && rest >= cnt[q]) { rest -= cnt[q]; k = q - 1; }
         tile = ((const AS4 int32_t*)(uintptr_t)rp.tile_lists)[(size_t)k * (rp.tiles_x * rp.n_bands_local) + rest];
+#ifdef RTX_WAVE_TRACE
+        wt_class = k;
+#endif
     }
+    // pixel of the tile this lane works for; in a split wave only the first 64 >> S lanes have one
+    const int pl = SPLIT ? (((sub << (6 - S)) | lane) & 63) : lane;
+    const bool spare = SPLIT && lane >= (64 >> S);
+    bool waiting = false;                 // the lane is back at a frame whose refracted child a helper traces, and waits for the colour
+    bool task_root = false;               // the lane's stack root is a handed-over child: post the colour instead of writing a pixel
+    int wait_h = 0;                       // ... from this helper lane
+    unsigned pend = 0;                    // bit i: frames[i] has a refracted child that is neither started nor handed over yet
     const int tx = tile % rp.tiles_x, bl = tile / rp.tiles_x;
     const int band = rp.band_first + bl * rp.band_stride;
 
@@ -311,11 +363,15 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 #endif
 
     int mode;
+#ifdef RTX_WAVE_TRACE
+    unsigned wt_iters = 0;
+#endif
     // ---- Camera::ray_for_pixel (camera.rs:56-69); the ray goes to LDS slot 0
     {
-        int px = tx * RTX_TILE + (lane & 7);
-        int py = band * RTX_TILE + (lane >> 3);
+        int px = tx * RTX_TILE + (pl & 7);
+        int py = band * RTX_TILE + (pl >> 3);
         mode = (px < cam.hsize && py < cam.vsize) ? MODE_RADIANCE : MODE_DONE;
+        if (spare) mode = MODE_DONE;                              // the spare lanes of a split wave start idle
         if (PROBE) {
             // probe launch: one wave per 8x8 block of TILES (so its 64 rays stay coherent), lane -> centre pixel of a tile
             const int sx_n = (rp.tiles_x + 7) >> 3;
@@ -339,8 +395,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     }
     // Canvas::write_pixel + Color::to_rgb (canvas.rs:31-33, color.rs:40-48), the moment a lane's colour is final
     auto write_pixel = [&](double r, double g, double b) {
-        const int px = tx * RTX_TILE + (lane & 7);
-        const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : (band * RTX_TILE + (lane >> 3));
+        const int px = tx * RTX_TILE + (pl & 7);
+        const int row = rp.compact ? (bl * RTX_TILE + (pl >> 3)) : (band * RTX_TILE + (pl >> 3));
         const size_t idx = (size_t)row * cam.hsize + px;
         rgb[idx * 3 + 0] = quantise(r);
         rgb[idx * 3 + 1] = quantise(g);
@@ -351,7 +407,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     int remaining = rp.max_depth;         // budget of the color_at call being traced
     int sp = 0;                           // frames below sp wait for children
     Frame frames[RTX_MAX_DEPTH];
-    bool primary = true;
+    bool primary = !spare;                // (the spare lanes of a split wave never trace a primary ray)
     // the hit being shaded while its shadow rays are traced (PreparedComputations, world.rs:225-256)
     V3 hp = {0, 0, 0}, eyev = {0, 0, 0}, nv = {0, 0, 0};
     int hop = 0;                          // op index of the hit shape
@@ -367,11 +423,24 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     uint32_t* const ls_ = (uint32_t*)(lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + sc.csg_entries * 64) + lane;
 #define lt(i) lt_[(i) * 64]
 #define ls(i) ls_[(i) * 64]
+    // split mailboxes (after the CSG lists): colour [3][64] indexed by the SENDER's lane + a posted flag per lane.
+    // A lane posts at most once (then it retires), so one box per lane is enough for all levels.
+    // mb_state: 0 free, 1 a task is running on this lane, 2 its colour is posted and not yet taken
+    volatile double* const mb_ = lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + (sc.csg_entries * 64 * 12 + 7) / 8;
+    volatile int* const mb_state = (volatile int*)(mb_ + 3 * 64);
+    volatile int* const mb_rem = mb_state + 64;
+    if (SPLIT) mb_state[lane] = 0;
 
-    while (__any(mode != MODE_DONE)) {
+    int guard = 0;                        // SPLIT: a wave whose lanes wait for each other must still end (it cannot happen by
+                                          // construction — helpers never wait for their owners — but a hung wave hangs the GPU)
+    while (__any(mode != MODE_DONE || (SPLIT && waiting))) {
+        if (SPLIT && ++guard > 64 * (2 << RTX_MAX_DEPTH)) { if (lane == 0) overflow++; break; }
         TM(tm_shade);
         // ================================================================= TRACE
         // World::intersect (world.rs:111-118) for every lane's current ray.
+#ifdef RTX_WAVE_TRACE
+        wt_iters += (mode != MODE_DONE) ? 1 : 0;
+#endif
         if (mode == MODE_RADIANCE) n_radiance++;
         else if (mode == MODE_SHADOW) n_shadow++;
         EV(RTX_EV_LANE_SLOTS, 1);         // every lane, busy or not: 64 per wave trace
@@ -865,9 +934,13 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         if (mode == MODE_RADIANCE) {
             if (primary) {
                 primary = false;
+#ifdef RTX_WAVE_TRACE
+                if (false) {
+#else
                 if (hit_out && !PROBE) {
-                    const int px = tx * RTX_TILE + (lane & 7);
-                    const int row = rp.compact ? (bl * RTX_TILE + (lane >> 3)) : (band * RTX_TILE + (lane >> 3));
+#endif
+                    const int px = tx * RTX_TILE + (pl & 7);
+                    const int row = rp.compact ? (bl * RTX_TILE + (pl >> 3)) : (band * RTX_TILE + (pl >> 3));
                     hit_out[(size_t)row * cam.hsize + px] = best_op >= 0 ? sc.hits[best_op].shape : -1;
                 }
             }
@@ -1044,6 +1117,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 f.R = R; f.refl = refl; f.transp = transp;
                 f.remaining = remaining;
                 if (do_refl) {
+                    if (SPLIT && do_refr) pend |= 1u << sp;
                     f.flags = FR_REFL | (do_refr ? FR_REFR_PENDING : 0) | (both ? FR_BOTH : 0);
                     if (do_refr) { f.o2[0] = fo.x; f.o2[1] = fo.y; f.o2[2] = fo.z; f.d2[0] = fd.x; f.d2[1] = fd.y; f.d2[2] = fd.z; }
                     nro = hp + nv * 1e-10;                                        // over_point
@@ -1061,9 +1135,65 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 
         TMS(tm_body);
         // ---- unwind: hand finished colours to the waiting frames (post-order)
+        if (SPLIT) {
+            // ---- hand refracted children to idle lanes of the same pixel group (uniform control flow: two ballots)
+            const bool idle = mode == MODE_DONE && !waiting && !returning && mb_state[lane] == 0;
+            // a lane offers the refracted child of its SHALLOWEST frame that still has one (the largest subtree)
+            // ... and only when it is about to trace a radiance ray itself: lanes alternate radiance and shadow
+            // traces, and a wave whose lanes do so in step runs one shading block per iteration instead of both
+            const bool want = pend != 0 && mode == MODE_RADIANCE;
+            const unsigned long long Dm = __ballot(want), Im = __ballot(idle);
+            if (Dm != 0 && Im != 0) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int n_don = (int)__builtin_popcountll(Dm), n_idle = (int)__builtin_popcountll(Im);
+                if (want) {
+                    // the k-th donor of the wave gets the k-th idle lane
+                    int r = (int)__builtin_popcountll(Dm & below);
+                    if (r < n_idle) {
+                        int target = 0;
+#pragma unroll
+                        for (int w = 32; w > 0; w >>= 1) {
+                            const int c = (int)__builtin_popcountll(Im & (((1ull << w) - 1ull) << target));
+                            if (r >= c) { r -= c; target += w; }
+                        }
+                        const int level = __builtin_ctz(pend);
+                        pend &= pend - 1u;
+                        Frame& f = frames[level];
+                        double* hs = lds_rays + target;            // the helper's ray slot 0
+                        hs[0] = f.o2[0]; hs[64] = f.o2[1]; hs[128] = f.o2[2]; hs[192] = f.d2[0]; hs[256] = f.d2[1]; hs[320] = f.d2[2];
+                        mb_rem[target] = f.remaining - 1;
+                        mb_state[target] = 1;
+                        f.flags = (f.flags & ~FR_REFR_PENDING) | FR_REMOTE | (target << FR_HELPER_SHIFT);
+                    }
+                }
+                if (idle && (int)__builtin_popcountll(Im & below) < n_don) {
+                    // this idle lane was paired: start the subtree as a color_at call of its own
+                    mode = MODE_RADIANCE;
+                    remaining = mb_rem[lane];
+                    sp = 0;
+                    task_root = true;
+                    primary = false;      // (a lane whose own pixel lies outside the image has never shaded)
+                }
+            }
+            if (waiting) {
+                // back at a frame with a remote child: has the helper posted the colour?
+                const int h = wait_h;
+                if (mb_state[h] == 2) {
+                    rr = mb_[h]; rg = mb_[64 + h]; rb = mb_[128 + h];
+                    mb_state[h] = 0;
+                    waiting = false;
+                    returning = true;     // the frame carries FR_SECOND: "refracted child finished" below
+                }
+            }
+        }
         while (returning) {
             if (sp == 0) {
-                if (!PROBE) write_pixel(rr, rg, rb);
+                if (SPLIT && task_root) {
+                    // a handed-over child is done: post what color_at returned; the frame's owner takes it from here
+                    mb_[lane] = rr; mb_[64 + lane] = rg; mb_[128 + lane] = rb;
+                    mb_state[lane] = 2;
+                    task_root = false;
+                } else if (!PROBE) write_pixel(rr, rg, rb);
                 mode = MODE_DONE;
                 returning = false;
             } else {
@@ -1084,12 +1214,23 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     if (fl & FR_BOTH) { s0 = s0 + ar * R; s1 = s1 + ag * R; s2 = s2 + ab * R; }
                     else { s0 = s0 + ar; s1 = s1 + ag; s2 = s2 + ab; }
                     if (fl & FR_REFR_PENDING) {
+                        if (SPLIT) pend &= ~(1u << (sp - 1));
                         f.s[0] = s0; f.s[1] = s1; f.s[2] = s2;
                         f.flags = fl | FR_SECOND;
                         nro = V3{f.o2[0], f.o2[1], f.o2[2]}; nrd = V3{f.d2[0], f.d2[1], f.d2[2]};
                         newray = true;
                         remaining = f.remaining - 1;
                         mode = MODE_RADIANCE;
+                        returning = false;
+                        continue;
+                    }
+                    if (SPLIT && (fl & FR_REMOTE)) {
+                        // the refracted child runs on a helper lane: park here until its colour is posted
+                        f.s[0] = s0; f.s[1] = s1; f.s[2] = s2;
+                        f.flags = fl | FR_SECOND;
+                        waiting = true;
+                        wait_h = (fl >> FR_HELPER_SHIFT) & 63;
+                        mode = MODE_DONE;
                         returning = false;
                         continue;
                     }
@@ -1161,6 +1302,18 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         }
         return;
     }
+#ifdef RTX_WAVE_TRACE
+    if (hit_out) {
+        unsigned it = wt_iters;
+        for (int o = 32; o > 0; o >>= 1) { unsigned v = __shfl_xor(it, o, 64); it = v > it ? v : it; }
+        if (lane == 0) {
+            const size_t wt_i = blockIdx.x + (SPLIT ? (size_t)rp.tiles_x * rp.n_bands_local : 0);
+            hit_out[3 * wt_i] = (int)wt_start;
+            hit_out[3 * wt_i + 1] = (int)(unsigned)__builtin_amdgcn_s_memrealtime();
+            hit_out[3 * wt_i + 2] = (int)(it | (S ? 0x10000u : 0u) | ((unsigned)wt_class << 17));
+        }
+    }
+#endif
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
@@ -1185,14 +1338,25 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
                                              int count_events, hipStream_t stream) {
-    const int blocks = rp->probe ? ((rp->tiles_x + 7) / 8) * ((rp->n_bands_local + 7) / 8) : rp->tiles_x * rp->n_bands_local;
+    int blocks = rp->probe ? ((rp->tiles_x + 7) / 8) * ((rp->n_bands_local + 7) / 8) : rp->tiles_x * rp->n_bands_local;
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double) + (size_t)sc->csg_entries * 64 * 12;
+    const bool split = !rp->probe && rp->use_lists && rp->split_cap > 0 && rp->split_launch;
+    if (split) blocks = rp->split_cap << RTX_SPLIT_BITS;
+    size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 7) & ~(size_t)7);
+    if (split) lds += 64 * (3 * sizeof(double) + 2 * sizeof(int));
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
     if (rp->probe) {
         if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
         else     hipLaunchKernelGGL((trace_shade_kernel<false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+    } else if (split) {
+        if (count_events) {
+            if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+            else     hipLaunchKernelGGL((trace_shade_kernel<false, true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+        } else {
+            if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+            else     hipLaunchKernelGGL((trace_shade_kernel<false, false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
+        }
     } else if (count_events) {
         if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
         else     hipLaunchKernelGGL((trace_shade_kernel<false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);

@@ -271,3 +271,57 @@ def test_cli_all_cameras(ctx, tmp_path):
     for k, name in enumerate(["two.png", "two.cam1.png"]):
         img = np.asarray(Image.open(str(tmp_path / name)))
         assert np.array_equal(img, ctx.render(pw, pcs[k], 5)["rgb"]), name
+
+
+@pytest.mark.parametrize("name,w,h", [("S4", 333, 171), ("S4", 640, 360), ("S5", 320, 200), ("S1", 200, 100)])
+def test_split_tiles_do_not_change_the_image(ctx, monkeypatch, name, w, h):
+    """Split tiles (SPLIT launch: the most expensive tiles rendered by 4 waves of 16 pixels each, refracted
+    children handed to idle lanes through LDS mailboxes, every sum still evaluated by the frame's owner in the
+    reference's order) are scheduling only: image, hit ids, ray counts and every reference-defined event count
+    equal the unsplit render's."""
+    import rtapi
+    import rtx
+    text = parity.scene_text(name, w, h)
+    pw, pc = rtx.load_yaml(text)
+    sc = ctx.scene(pw)
+    try:
+        monkeypatch.setenv("RTX_LPT", "1")
+        monkeypatch.setenv("RTX_SPLIT", "0")
+        a = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
+        monkeypatch.setenv("RTX_SPLIT", "1")
+        monkeypatch.setenv("RTX_SPLIT_CLASS", "4")
+        b = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
+        monkeypatch.delenv("RTX_SPLIT_CLASS")
+        c = sc.render(pc[0], 5)
+        for r in (b, c):
+            assert np.array_equal(a["rgb"], r["rgb"]) and np.array_equal(a["hit"], r["hit"])
+            assert (a["stats"].rays_primary, a["stats"].rays_shadow, a["stats"].rays_secondary) == \
+                (r["stats"].rays_primary, r["stats"].rays_shadow, r["stats"].rays_secondary)
+        ea, eb = a["stats"].events(), b["stats"].events()
+        assert {k: ea[k] for k in rtapi.REF_EVENTS} == {k: eb[k] for k in rtapi.REF_EVENTS}
+        rgb = np.zeros_like(a["rgb"]); hit = np.full_like(a["hit"], -7)
+        for g in range(3):
+            sc.render(pc[0], 5, bands=(g, 3), out=(rgb, hit))
+        assert np.array_equal(rgb, a["rgb"]) and np.array_equal(hit, a["hit"])
+    finally:
+        sc.close()
+
+
+def test_split_tiles_on_the_torture_scene(ctx, monkeypatch):
+    """The same invariance on the API-built torture scene (glass inside groups and CSG, two lights): the CSG
+    instantiation of the SPLIT kernel hands refracted children between lanes there."""
+    import rtapi
+    import rtx
+    import torture
+    pw, pc = torture.build(rtx.API)
+    monkeypatch.setenv("RTX_LPT", "1")
+    monkeypatch.setenv("RTX_SPLIT", "0")
+    a = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS)
+    monkeypatch.setenv("RTX_SPLIT", "1")
+    for cls in ("1", "4", "6"):
+        monkeypatch.setenv("RTX_SPLIT_CLASS", cls)
+        b = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS)
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"]), cls
+        assert a["stats"].rays == b["stats"].rays
+        ea, eb = a["stats"].events(), b["stats"].events()
+        assert {k: ea[k] for k in rtapi.REF_EVENTS} == {k: eb[k] for k in rtapi.REF_EVENTS}, cls

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Split tiles (RTX_SPLIT / RTX_SPLIT_CLASS, read at every render): kernel ms of one rank's share of the 4K frame
+for N = 1, 2, 4, 8 and of smaller whole frames, unsplit against splitting classes >= 7, 6, 5, 4."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ray-tracer_amd", "python"), os.path.join(ROOT, "tools")]
+import rtx, scenes
+ctx = rtx.Context(0)
+CLS = os.environ.get("PROBE_CLASSES", "7,6,5,4").split(",")     # split classes >= c
+
+
+def best(sc, cam, bands, reps=5):
+    return min(sc.render(cam, 5, bands=bands, flags=rtx.F_BANDS_COMPACT, want_hit=False)["stats"].kernel_ms for _ in range(reps))
+
+
+def row(sc, cam, bands):
+    os.environ["RTX_SPLIT"] = "0"
+    out = ["unsplit %.3f" % best(sc, cam, bands)]
+    os.environ["RTX_SPLIT"] = "1"
+    for c in CLS:
+        os.environ["RTX_SPLIT_CLASS"] = c
+        out.append("%s %.3f" % (c, best(sc, cam, bands)))
+    return "  ".join(out)
+
+
+name = sys.argv[1] if len(sys.argv) > 1 else "S4"
+world, cams = rtx.load_yaml(scenes.make(name, width=3840, height=2160))
+sc = ctx.scene(world)
+for N in (2, 4, 8):
+    print("%s 4K N=%d rank0 kernel ms: %s" % (name, N, row(sc, cams[0], (0, N))), flush=True)
+sc.close()
+for w, h in ((1920, 1080), (1280, 720)):
+    world, cams = rtx.load_yaml(scenes.make(name, width=w, height=h))
+    sc = ctx.scene(world)
+    print("%s %dx%d kernel ms: %s" % (name, w, h, row(sc, cams[0], (0, 1))), flush=True)
+    sc.close()
