@@ -241,7 +241,10 @@ def test_batch_of_cameras_equals_single_renders(ctx, monkeypatch):
             assert np.array_equal(batch[k]["rgb"], one["rgb"]) and np.array_equal(batch[k]["hit"], one["hit"]), k
             bs, os_ = batch[k]["stats"], one["stats"]
             assert (bs.rays_primary, bs.rays_shadow, bs.rays_secondary) == (os_.rays_primary, os_.rays_shadow, os_.rays_secondary)
-            assert bs.events() == os_.events() and bs.kernel_ms > 0
+            # (lane_slots / op_slots count wave iterations: they depend on which tiles the launch happened to split)
+            be, oe = bs.events(), os_.events()
+            assert {k: v for k, v in be.items() if k not in ("lane_slots", "op_slots")} == \
+                {k: v for k, v in oe.items() if k not in ("lane_slots", "op_slots")} and bs.kernel_ms > 0
         monkeypatch.delenv("RTX_LPT")
         plain = sc.render_batch(pcs, 5, want_hit=False, want_stats=False)
         assert all(np.array_equal(plain[k]["rgb"], batch[k]["rgb"]) for k in range(4))
