@@ -1,3 +1,5 @@
+"""One-off randomized parity sweep (not collected by pytest): python tests/sweep_fuzz.py on a GPU box.
+Test infrastructure: compares the HIP path with the oracle on generated scene files (tests/fuzz_scenes.py)."""
 import sys, os
 ROOT = os.getcwd()
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "ray-tracer_amd/python"), os.path.join(ROOT, "oracle")]
