@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     // ---- state that survives a traversal (everything else is rebuilt or re-read):
     int remaining = rp.max_depth;         // budget of the color_at call being traced
     int sp = 0;                           // frames below sp wait for children
-    Frame frames[RTX_MAX_DEPTH];
+    Frame frames[RTX_MAX_DEPTH + 1];      // + 1: the hit at budget 0 (sp == max_depth) still parks its partial light sum in frames[sp]
     bool primary = !spare;                // (the spare lanes of a split wave never trace a primary ray)
     // the hit being shaded while its shadow rays are traced (PreparedComputations, world.rs:225-256)
     V3 hp = {0, 0, 0}, eyev = {0, 0, 0}, nv = {0, 0, 0};

@@ -335,7 +335,8 @@ def test_randomized_scene_files_parity(ctx):
     pattern transforms, mirror / glass / tinted materials, planes inside groups, negative scales, 1-2 lights): every
     generated file is rendered through the C ABI and by the oracle; ids, colours (the bar), ray counts and
     reference-defined event counts must agree.  Scenes beyond a documented kernel limit (RTX_E_CAPACITY /
-    RTX_E_UNSUPPORTED) are skipped and counted."""
+    RTX_E_UNSUPPORTED) are skipped and counted.  The depth budget cycles through 5 (the reference's, camera.rs:42), 0, 1,
+    3 and 8 (= RTX_MAX_DEPTH: the whole frame stack)."""
     import fuzz_scenes
     import ora
     import rtapi
@@ -345,23 +346,24 @@ def test_randomized_scene_files_parity(ctx):
     done = skipped = ties = 0
     for i in range(40):
         text = fuzz_scenes.make(rng)
+        depth = (5, 0, 1, 3, 8)[i % 5]
         pw, pcs = rtx.load_yaml(text)
         try:
-            gpu = ctx.render(pw, pcs[0], 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+            gpu = ctx.render(pw, pcs[0], depth, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
         except rtx.RtxError as e:
             assert e.code in (rtx.E_CAPACITY, rtx.E_UNSUPPORTED), (i, str(e))
             skipped += 1
             continue
         ow, ocs = yaml_scene.load(text, ora.API)
-        cpu = ora.render(ow, ocs[0], 5, threads=8)
-        r = parity.assert_parity(gpu, cpu, "generated scene %d\n%s" % (i, text))
+        cpu = ora.render(ow, ocs[0], depth, threads=8)
+        r = parity.assert_parity(gpu, cpu, "generated scene %d depth %d\n%s" % (i, depth, text))
         gs, cs = gpu["stats"], cpu["stats"]
         if r["tie_pixels"] == 0:
             # (a tie pixel may legitimately follow another branch of the ray tree, so its rays differ)
             assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), (i, r)
             ge, ce = gs.events(), cs.events()
             assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}, i
-        fast = ctx.render(pw, pcs[0], 5)
+        fast = ctx.render(pw, pcs[0], depth)
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
         ties += r["tie_pixels"]; done += 1
     assert done >= 30, (done, skipped)
