@@ -1,0 +1,39 @@
+"""One-off randomized parity sweep over API-built scene graphs (not collected by pytest):
+python tests/sweep_fuzz_api.py [seeds] on a GPU box.  Test infrastructure (uses the oracle)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "ray-tracer_amd/python"), os.path.join(ROOT, "oracle")]
+import numpy as np, fuzz_api, rtx, ora, parity, rtapi
+ctx = rtx.Context(0)
+bad = skipped = ties = tie_scenes = tie_mis = n = 0
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+    rng = np.random.default_rng(5000 + seed)
+    for i in range(150):
+        p = fuzz_api.plan(rng, int(rng.integers(8, 120)), int(rng.integers(8, 90)))
+        depth = (5, 0, 1, 2, 3, 8, 7, 4)[i % 8]
+        pw, pc = fuzz_api.build(rtx.API, p)
+        try:
+            gpu = ctx.render(pw, pc, depth, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+        except rtx.RtxError as e:
+            if e.code not in (rtx.E_CAPACITY, rtx.E_UNSUPPORTED):
+                print("ERROR seed", seed, "scene", i, e, flush=True); bad += 1
+            skipped += 1; continue
+        ow, oc = fuzz_api.build(ora.API, p)
+        cpu = ora.render(ow, oc, depth, threads=16)
+        r = parity.compare(gpu, cpu)
+        gs, cs = gpu["stats"], cpu["stats"]
+        ok = r["id_mismatch"] == 0 and r["within1"] >= 0.999
+        if r["tie_pixels"] == 0:
+            ok = ok and gs.rays == cs.rays
+            ge, ce = gs.events(), cs.events()
+            ok = ok and all(ge[k] == ce[k] for k in rtapi.REF_EVENTS if k != "pow")
+        os.environ["RTX_LPT"] = "1"; os.environ["RTX_SPLIT"] = "1"; os.environ["RTX_SPLIT_CLASS"] = "2"
+        fast = ctx.render(pw, pc, depth)
+        del os.environ["RTX_LPT"], os.environ["RTX_SPLIT"], os.environ["RTX_SPLIT_CLASS"]
+        ok = ok and np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]) and fast["stats"].rays == gs.rays
+        ties += r["tie_pixels"]; tie_scenes += 1 if r["tie_pixels"] else 0; tie_mis += r["id_mismatch_incl_ties"]; n += 1
+        if not ok:
+            bad += 1
+            print("MISMATCH seed", seed, "scene", i, "depth", depth, r, gs.rays, cs.rays, flush=True)
+    print("seed", seed, "done; scenes", n, "bad", bad, "skipped", skipped, "tie pixels", ties, flush=True)
+print("TOTAL scenes", n, "bad", bad, "skipped", skipped, "scenes with ties", tie_scenes, "id mismatches inside tie pixels", tie_mis)

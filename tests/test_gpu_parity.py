@@ -367,3 +367,36 @@ def test_randomized_scene_files_parity(ctx):
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
         ties += r["tie_pixels"]; done += 1
     assert done >= 30, (done, skipped)
+
+
+def test_randomized_api_scene_graphs_parity(ctx):
+    """Randomized scene GRAPHS through the WorldBuilder API (tests/fuzz_api.py): groups as CSG operands, CSG inside
+    groups, empty groups, lists of more than 32 children, nesting up to 7, planes anywhere, 0-3 lights — structures
+    the scene DSL cannot express.  Same checks as for the generated scene files, depth budgets 0..8."""
+    import fuzz_api
+    import ora
+    import rtapi
+    import rtx
+    rng = np.random.default_rng(20261112)
+    done = 0
+    for i in range(40):
+        p = fuzz_api.plan(rng)
+        depth = (5, 0, 2, 8)[i % 4]
+        pw, pc = fuzz_api.build(rtx.API, p)
+        try:
+            gpu = ctx.render(pw, pc, depth, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+        except rtx.RtxError as e:
+            assert e.code in (rtx.E_CAPACITY, rtx.E_UNSUPPORTED), (i, str(e))
+            continue
+        ow, oc = fuzz_api.build(ora.API, p)
+        cpu = ora.render(ow, oc, depth, threads=8)
+        r = parity.assert_parity(gpu, cpu, "generated graph %d depth %d" % (i, depth))
+        if r["tie_pixels"] == 0:
+            gs, cs = gpu["stats"], cpu["stats"]
+            assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), (i, r)
+            ge, ce = gs.events(), cs.events()
+            assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}, i
+        fast = ctx.render(pw, pc, depth)
+        assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
+        done += 1
+    assert done >= 30
