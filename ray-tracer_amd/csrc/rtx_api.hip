@@ -197,7 +197,6 @@ struct Compiler {
         if (node < 0 || node >= d->n_nodes) { bad(RTX_E_INVALID, "node id out of range"); return 0; }
         if (seen[node]) { bad(RTX_E_INVALID, "node " + std::to_string(node) + " reachable twice (not a tree)"); return 0; }
         seen[node] = 1;
-        if (level >= RTX_MAX_LEVELS) { bad(RTX_E_CAPACITY, "container nesting deeper than RTX_MAX_LEVELS"); return 0; }
         const int kind = d->node_kind[node];
         const int lf = list ? OPF_LIST : 0;
         if (kind == RTX_NODE_SPHERE || kind == RTX_NODE_PLANE || kind == RTX_NODE_CUBE) {
@@ -219,6 +218,7 @@ struct Compiler {
             return kind == RTX_NODE_PLANE ? 1 : 2;
         }
         if (kind != RTX_NODE_GROUP && kind != RTX_NODE_CSG) { bad(RTX_E_INVALID, "unknown node kind"); return 0; }
+        if (level >= RTX_MAX_LEVELS) { bad(RTX_E_CAPACITY, "container nesting deeper than RTX_MAX_LEVELS"); return 0; }
         const int fc = d->node_first_child[node], nc = d->node_child_count[node];
         if (nc < 0 || fc < 0 || fc + nc > d->n_children) { bad(RTX_E_INVALID, "children range out of bounds"); return 0; }
         if (level > max_container_level) max_container_level = level;

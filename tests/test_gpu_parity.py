@@ -400,3 +400,61 @@ def test_randomized_api_scene_graphs_parity(ctx):
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
         done += 1
     assert done >= 30
+
+
+def test_kernel_limits_are_reported_not_truncated(ctx):
+    """The bounded structures of the kernel (include/rtx.h: RTX_MAX_CSG_ENTRIES, RTX_MAX_CSG_NEST, RTX_MAX_LEVELS) and the
+    affine-only rule are validated when the scene is created: a scene beyond them is an error code, never a silently
+    wrong image; a scene exactly at a limit renders and matches the oracle."""
+    import ora
+    import rtapi
+    import rtx
+
+    def chain(api, n_leaves):
+        """union(union(...union(s0, s1)..., s_{n-2}), s_{n-1}): n_leaves shapes under one CSG root."""
+        w = api.world_new()
+        node = rtapi.shape(w.add_shape(rtapi.SPHERE, None, api.translation(-2.0, 0.5, 0)))
+        for k in range(1, n_leaves):
+            s = rtapi.shape(w.add_shape(rtapi.SPHERE if k % 2 else rtapi.CUBE, None,
+                                        api.compose([("scale", [0.5, 0.5, 0.5]), ("translate", [-2.0 + 0.55 * k, 0.5, 0.1 * k])])))
+            node = rtapi.csg(w.add_csg(rtapi.UNION, node, s))
+        w.add_object_to_scene(node)
+        w.add_light([-5, 8, -8], [1, 1, 1])
+        w.build()
+        return w, api.camera(96, 48, 1.0, api.view_transform([0, 2, -9], [0, 0.5, 0], [0, 1, 0]))
+
+    def nested_groups(api, depth):
+        w = api.world_new()
+        g = w.add_group(api.translation(0, 0.1, 0))
+        w.add_object_to_scene(rtapi.group(g))
+        for _ in range(depth - 1):
+            h = w.add_group(api.compose([("rotate-y", 0.1), ("translate", [0.05, 0.02, 0])]))
+            w.set_group_of(rtapi.group(h), g)
+            g = h
+        w.set_group_of(rtapi.shape(w.add_shape(rtapi.SPHERE)), g)
+        w.add_light([-5, 8, -8], [1, 1, 1])
+        w.build()
+        return w, api.camera(64, 48, 1.0, api.view_transform([0, 1, -6], [0, 0.5, 0], [0, 1, 0]))
+
+    # exactly at the limits: 8 leaf shapes under one CSG root (16 list entries), 16 nested groups
+    for builder, arg in ((chain, 8), (nested_groups, 16)):
+        pw, pc = builder(rtx.API, arg)
+        ow, oc = builder(ora.API, arg)
+        gpu = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+        cpu = ora.render(ow, oc, 5, threads=8)
+        parity.assert_parity(gpu, cpu, "%s(%d)" % (builder.__name__, arg))
+        assert gpu["stats"].rays == cpu["stats"].rays and (gpu["hit"] >= 0).any()
+    # one past them
+    for builder, arg in ((chain, 9), (nested_groups, 17)):
+        pw, pc = builder(rtx.API, arg)
+        with pytest.raises(rtx.RtxError) as e:
+            ctx.render(pw, pc, 5)
+        assert e.value.code == rtx.E_CAPACITY, (builder.__name__, arg, str(e.value))
+    # a projective (non-affine) transform cannot come out of the scene DSL; the API rejects it
+    w = rtx.API.world_new()
+    m = rtx.API.identity(); m[3] = 0.25                       # bottom row (0.25, 0, 0, 1)
+    w.add_object_to_scene(rtapi.shape(w.add_shape(rtapi.SPHERE, None, m)))
+    w.build()
+    with pytest.raises(rtx.RtxError) as e:
+        ctx.render(w, rtx.API.camera(16, 16, 1.0), 5)
+    assert e.value.code == rtx.E_UNSUPPORTED
