@@ -31,6 +31,26 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         fast = ctx.render(pw, pc, depth)
         del os.environ["RTX_LPT"], os.environ["RTX_SPLIT"], os.environ["RTX_SPLIT_CLASS"]
         ok = ok and np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]) and fast["stats"].rays == gs.rays
+        if i % 5 == 0:
+            # band subsets (row-interleaved, plain and compact) and a batch of two cameras against single renders
+            sc = ctx.scene(pw)
+            rgb = np.zeros_like(gpu["rgb"]); hit = np.full_like(gpu["hit"], -7)
+            G = 2 + i % 3
+            for g in range(G):
+                sc.render(pc, depth, bands=(g, G), out=(rgb, hit))
+            ok = ok and np.array_equal(rgb, gpu["rgb"]) and np.array_equal(hit, gpu["hit"])
+            nb = (pc.vsize + 7) // 8
+            for g in range(G):
+                c = sc.render(pc, depth, bands=(g, G), flags=rtx.F_BANDS_COMPACT)
+                rows = np.concatenate([np.arange(b * 8, min(b * 8 + 8, pc.vsize)) for b in range(g, nb, G)] or [np.zeros(0, int)])
+                ok = ok and np.array_equal(c["rgb"][:len(rows)], gpu["rgb"][rows])
+            pc2 = rtx.API.camera(max(8, pc.hsize // 2), pc.vsize + 3, 0.9, rtx.API.view_transform([3, 4, -9], [0, 1, 0], [0, 1, 0]))
+            batch = sc.render_batch([pc, pc2, pc], depth)
+            one2 = sc.render(pc2, depth)
+            ok = ok and np.array_equal(batch[0]["rgb"], gpu["rgb"]) and np.array_equal(batch[2]["hit"], gpu["hit"])
+            ok = ok and np.array_equal(batch[1]["rgb"], one2["rgb"]) and np.array_equal(batch[1]["hit"], one2["hit"])
+            ok = ok and batch[1]["stats"].rays == one2["stats"].rays
+            sc.close()
         ties += r["tie_pixels"]; tie_scenes += 1 if r["tie_pixels"] else 0; tie_mis += r["id_mismatch_incl_ties"]; n += 1
         if not ok:
             bad += 1
