@@ -22,7 +22,11 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         cpu = ora.render(ow, oc, depth, threads=16)
         r = parity.compare(gpu, cpu)
         gs, cs = gpu["stats"], cpu["stats"]
-        ok = r["id_mismatch"] == 0 and r["within1"] >= 0.999
+        # (the images are tiny, so one pixel is already > 0.1 %: colours are compared away from the oracle's tie pixels,
+        # where a different branch of the ray tree is legitimate)
+        away = cpu["tie"] == 0
+        diff = np.abs(gpu["rgb"].astype(np.int16) - cpu["rgb"].astype(np.int16)).max(axis=2)
+        ok = r["id_mismatch"] == 0 and not (diff[away] > 1).any()
         if r["tie_pixels"] == 0:
             ok = ok and gs.rays == cs.rays
             ge, ce = gs.events(), cs.events()
