@@ -458,3 +458,74 @@ def test_kernel_limits_are_reported_not_truncated(ctx):
     with pytest.raises(rtx.RtxError) as e:
         ctx.render(w, rtx.API.camera(16, 16, 1.0), 5)
     assert e.value.code == rtx.E_UNSUPPORTED
+
+
+class _Hip:
+    """Minimal ctypes view of the HIP runtime librtx_hip.so itself is linked against (device buffers and a stream
+    for the rtx_render_device test; torch is deliberately not involved: it brings a HIP runtime of its own)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+        self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.lib.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.lib.hipStreamDestroy.argtypes = [C.c_void_p]
+
+    def malloc(self, n, fill=0):
+        p = self.C.c_void_p()
+        assert self.lib.hipMalloc(self.C.byref(p), n) == 0
+        assert self.lib.hipMemset(p, fill, n) == 0
+        return p
+
+    def to_host(self, p, n, dtype):
+        out = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        assert self.lib.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), p, n, 2) == 0      # hipMemcpyDeviceToHost
+        return out
+
+
+def test_render_device_writes_device_buffers_on_the_callers_stream(ctx):
+    """rtx_render_device (the entry point bench.py and a multi-GPU host use): outputs are device pointers, the work
+    is queued on the caller's stream and nothing is copied.  Full frame with hit ids and stats, then asynchronous
+    compact band sets of 3 ranks reassembled on the host, must equal rtx_render's image."""
+    import ctypes as C
+    import rtx
+    hip = _Hip()
+    text = parity.scene_text("S4", 333, 171)
+    pw, pc = rtx.load_yaml(text)
+    sc = ctx.scene(pw)
+    st = C.c_void_p()
+    assert hip.lib.hipStreamCreate(C.byref(st)) == 0
+    bufs = []
+    try:
+        want = sc.render(pc[0], 5)
+        H, W = pc[0].vsize, pc[0].hsize
+        rgb = hip.malloc(H * W * 3); hit = hip.malloc(H * W * 4, 0xee)
+        bufs += [rgb, hit]
+        stats = sc.render_device(pc[0], rgb.value, hit.value, 5, stream=st.value, stats=True)
+        assert stats.rays == want["stats"].rays and stats.kernel_ms > 0
+        assert np.array_equal(hip.to_host(rgb, H * W * 3, np.uint8).reshape(H, W, 3), want["rgb"])
+        assert np.array_equal(hip.to_host(hit, H * W * 4, np.int32).reshape(H, W), want["hit"])
+        out = np.zeros_like(want["rgb"])
+        parts = []
+        for g in range(3):
+            rows = rtx.LIB.rtx_band_rows(H, rtx.Bands(g, 3))
+            b = hip.malloc(rows * W * 3)
+            bufs.append(b)
+            assert sc.render_device(pc[0], b.value, 0, 5, bands=(g, 3), flags=rtx.F_BANDS_COMPACT, stream=st.value) is None
+            parts.append((g, rows, b))
+        assert hip.lib.hipStreamSynchronize(st) == 0                 # the three launches were only queued
+        for g, rows, b in parts:
+            img = hip.to_host(b, rows * W * 3, np.uint8).reshape(rows, W, 3)
+            ys = np.concatenate([np.arange(k * 8, min(k * 8 + 8, H)) for k in range(g, (H + 7) // 8, 3)])
+            out[ys] = img[:len(ys)]
+        assert np.array_equal(out, want["rgb"])
+    finally:
+        sc.close()
+        for b in bufs:
+            hip.lib.hipFree(b)
+        hip.lib.hipStreamDestroy(st)
