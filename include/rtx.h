@@ -147,9 +147,23 @@ int  rtx_render(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rt
 
 /* Same, but the outputs are DEVICE pointers on the context's device and the launch is queued on
  * `stream` (a hipStream_t, NULL = the context's own stream) without a host copy; used when the
- * caller gathers bands with RCCL.  Synchronises only if stats != NULL. */
+ * caller gathers bands itself.  Synchronises only if stats != NULL; without stats a device-side overflow is
+ * reported through the sticky error of rtx_ctx_poll() below. */
 int  rtx_render_device(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
                        uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats);
+
+/* Asynchronous renders (rtx_render_device without stats, rtx_render_device_noalloc) cannot return a device-side
+ * RTX_E_CAPACITY themselves.  The condition is STICKY instead: the launch raises a flag in pinned host memory, the next
+ * rtx_render_device* call on the context refuses to queue more work and returns RTX_E_CAPACITY, and
+ * rtx_ctx_poll(ctx, wait) returns it (after waiting for the last queued render if wait != 0) and clears it.
+ * The reference panics instead (intersections.rs:31, main.rs:27); nothing is ever silently truncated. */
+int  rtx_ctx_poll(rtx_ctx*, int wait);
+
+/* Scheduling knobs of a context (they never change an image).  Defaults come from the environment
+ * ONCE, at rtx_init (RTX_LPT, RTX_TILE_MUL, RTX_PROBE_DEPTH, RTX_SPLIT, RTX_SPLIT_CLASS); names here: "lpt", "tile_mul",
+ * "probe_depth", "split", "split_class"; value -1 = the per-scene default for "lpt" and "split".
+ * No counterpart in the reference (it has no scheduler). */
+int  rtx_set_option(rtx_ctx*, const char* name, int value);
 
 /* SURVEY.md §8f N4 — several frames of ONE resident scene: all cameras of a scene file (yaml.rs:34 parses
  * every `add: camera`, main.rs:24 renders only cameras[0]) or an animation sweep.  Every frame's launches are

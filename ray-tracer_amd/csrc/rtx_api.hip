@@ -15,6 +15,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
+#include "rtx_internal.h"
 #include "rtx_pow.h"
 
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
@@ -39,45 +40,9 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
     out[i] = r;
 }
 
-struct rtx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    unsigned long long* d_counters = nullptr;
-    // scheduling state of one stream: tile class lists (grown on demand) and their fill counts.  lanes[0] runs
-    // on `stream`; lanes 1.. have streams of their own and are created by the first rtx_render_batch
-    // side/ev_fork/ev_join: the SPLIT launch of a frame runs on `side`, beside the main launch (created on first use)
-    struct Lane { hipStream_t stream = nullptr; int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0;
-                  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
-    static constexpr int kLanes = 4;
-    Lane lanes[kLanes];
-    uint8_t* h_stage = nullptr; size_t stage_cap = 0;                        // pinned staging of a batch's images
-    uint8_t* d_rgb = nullptr; size_t rgb_cap = 0;
-    int32_t* d_hit = nullptr; size_t hit_cap = 0;
-    unsigned long long* d_batch_counters = nullptr; size_t batch_cap = 0;   // one counter block per frame of a batch
-    std::string err;
-};
-
-struct rtx_scene {
-    rtx_ctx* ctx = nullptr;
-    SceneDev dev{};
-    void* d_ops = nullptr; void* d_bodies = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
-    void* d_materials = nullptr; void* d_lights = nullptr; void* d_pairs = nullptr;
-    void* d_chunks = nullptr; void* d_counts = nullptr; void* d_lcull = nullptr; void* d_lops = nullptr; void* d_conts = nullptr;
-};
-
 namespace {
 
-#define HIPCHK(ctx, call)                                                              \
-    do {                                                                               \
-        hipError_t e_ = (call);                                                        \
-        if (e_ != hipSuccess) {                                                        \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
-            return RTX_E_DEVICE;                                                       \
-        }                                                                              \
-    } while (0)
-
-int fail(rtx_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int fail(rtx_ctx* c, int code, const std::string& msg) { return rtx_fail(c, code, msg); }
 
 // column-major 4x4 -> rows 0..2 (row-major 3x4) + w33; false if the bottom row is not (0,0,0,*)
 bool affine_rows(const double* m, double* rows12, double* w33) {
@@ -369,6 +334,17 @@ const char* rtx_strerror(int code) {
 
 const char* rtx_last_error(const rtx_ctx* c) { return c ? c->err.c_str() : ""; }
 
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static void release_scene_memory(rtx_scene* s) {
+    (void)hipSetDevice(s->device);
+    for (void** p : {&s->d_ops, &s->d_bodies, &s->d_shapes, &s->d_paths, &s->d_materials, &s->d_lights, &s->d_pairs,
+                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
 int rtx_init(int device, rtx_ctx** out) {
     if (!out) return RTX_E_INVALID;
     *out = nullptr;
@@ -376,14 +352,34 @@ int rtx_init(int device, rtx_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RTX_E_DEVICE;
     rtx_ctx* c = new rtx_ctx();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void**)&c->lanes[0].d_tile_counts, 64 * sizeof(int32_t)) != hipSuccess) {
-        delete c;
+    // the scheduling knobs are read here, once; rtx_set_option() changes them afterwards
+    c->opt.lpt = env_int("RTX_LPT", -1);
+    c->opt.tile_mul = env_int("RTX_TILE_MUL", 7919);
+    c->opt.probe_depth = env_int("RTX_PROBE_DEPTH", 2);
+    c->opt.split = env_int("RTX_SPLIT", -1);
+    c->opt.split_class = env_int("RTX_SPLIT_CLASS", 6);
+    c->opt.debug = env_int("RTX_DEBUG", 0);
+    rtx_ctx::Lane& l0 = c->lanes[0];
+    void* sticky_dev = nullptr;
+    const bool ok =
+        hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
+        hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+        hipMalloc((void**)&c->d_counters, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long)) == hipSuccess &&
+        hipMalloc((void**)&l0.d_tile_counts, 64 * sizeof(int32_t)) == hipSuccess &&
+        // everything a queued render may need later is created here, so that rendering itself creates nothing
+        hipStreamCreateWithFlags(&l0.side, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&l0.ev_fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&l0.ev_join, hipEventDisableTiming) == hipSuccess &&
+        hipHostMalloc((void**)&c->h_counters, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
+        hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer(&sticky_dev, (void*)c->h_sticky, 0) == hipSuccess;
+    if (!ok) {
+        rtx_shutdown(c);
         return RTX_E_DEVICE;
     }
-    c->lanes[0].stream = c->stream;
+    *c->h_sticky = 0;
+    c->d_sticky = (unsigned long long*)sticky_dev;
+    l0.stream = c->stream;
     *out = c;
     return RTX_OK;
 }
@@ -391,6 +387,11 @@ int rtx_init(int device, rtx_ctx** out) {
 void rtx_shutdown(rtx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+    // scenes the caller has not destroyed yet: their device memory goes now, the handles stay valid for
+    // rtx_scene_destroy (which then only frees the host struct)
+    for (rtx_scene* s : c->scenes) { release_scene_memory(s); s->ctx = nullptr; }
+    c->scenes.clear();
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -404,10 +405,36 @@ void rtx_shutdown(rtx_ctx* c) {
         if (c->lanes[l].ev_join) (void)hipEventDestroy(c->lanes[l].ev_join);
     }
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_sticky) (void)hipHostFree((void*)c->h_sticky);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int rtx_set_option(rtx_ctx* c, const char* name, int value) {
+    if (!c || !name) return RTX_E_INVALID;
+    const std::string n(name);
+    if (n == "lpt") c->opt.lpt = value;
+    else if (n == "tile_mul") c->opt.tile_mul = value;
+    else if (n == "probe_depth") c->opt.probe_depth = value;
+    else if (n == "split") c->opt.split = value;
+    else if (n == "split_class") c->opt.split_class = value;
+    else if (n == "debug") c->opt.debug = value;
+    else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
+    return RTX_OK;
+}
+
+int rtx_ctx_poll(rtx_ctx* c, int wait) {
+    if (!c) return RTX_E_INVALID;
+    if (wait && c->last_stream) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    }
+    const int rc = rtx_check_sticky(c);
+    *c->h_sticky = 0;
+    return rc;
 }
 
 int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
@@ -446,7 +473,8 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         for (int k = 0; k < 3; k++) { lights[i].pos[k] = d->light_position[i * 3 + k]; lights[i].intensity[k] = d->light_intensity[i * 3 + k]; }
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    rtx_scene* s = new rtx_scene(); s->ctx = ctx;
+    rtx_scene* s = new rtx_scene(); s->ctx = ctx; s->device = ctx->device;
+    ctx->scenes.push_back(s);
     int rc;
     std::vector<OpHead> heads(cc.ops.size() + 2);
     std::vector<OpBody> bodies(cc.ops.size() + 1);
@@ -490,7 +518,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         heads[i].run = run;
     }
     for (size_t i = cc.ops.size(); i < heads.size(); i++) { heads[i].info = OPK_GROUP_END; heads[i].cull[3] = INFINITY; }   // padding, never executed
-    if (getenv("RTX_DEBUG"))
+    if (ctx->opt.debug)
         for (size_t i = 0; i < heads.size(); i++)
             fprintf(stderr, "head %zu: info=%08x skip=%d shape=%d cull=%g %g %g %g\n", i, heads[i].info, heads[i].skip,
                     heads[i].shape, heads[i].cull[0], heads[i].cull[1], heads[i].cull[2], heads[i].cull[3]);
@@ -522,31 +550,33 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
 
 void rtx_scene_destroy(rtx_scene* s) {
     if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
-    if (s->d_ops) (void)hipFree(s->d_ops);
-    if (s->d_bodies) (void)hipFree(s->d_bodies);
-    if (s->d_shapes) (void)hipFree(s->d_shapes);
-    if (s->d_paths) (void)hipFree(s->d_paths);
-    if (s->d_materials) (void)hipFree(s->d_materials);
-    if (s->d_lights) (void)hipFree(s->d_lights);
-    if (s->d_pairs) (void)hipFree(s->d_pairs);
-    for (void* p : {s->d_chunks, s->d_counts, s->d_lcull, s->d_lops, s->d_conts}) if (p) (void)hipFree(p);
+    if (s->ctx) {
+        // (renders queued asynchronously may still read the scene: wait for the last one before freeing)
+        (void)hipSetDevice(s->device);
+        if (s->ctx->last_stream) (void)hipStreamSynchronize(s->ctx->last_stream);
+        auto& v = s->ctx->scenes;
+        v.erase(std::remove(v.begin(), v.end(), s), v.end());
+        release_scene_memory(s);
+    }
     delete s;
 }
 
 int rtx_debug_math(rtx_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out) {
     if (!ctx || !a || !b || !out || n <= 0 || op < 0 || op > 8) return RTX_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    double* d = nullptr;                         // one allocation: a | b | out
     const size_t bytes = (size_t)n * sizeof(double);
-    HIPCHK(ctx, hipMalloc((void**)&da, bytes)); HIPCHK(ctx, hipMalloc((void**)&db, bytes)); HIPCHK(ctx, hipMalloc((void**)&dout, bytes));
-    HIPCHK(ctx, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, (long long)n, da, db, dout);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    HIPCHK(ctx, hipMalloc((void**)&d, 3 * bytes));
+    hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, (long long)n, d, d + n, d + 2 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, RTX_E_DEVICE, std::string("rtx_debug_math: ") + hipGetErrorString(e));
     return RTX_OK;
 }
 
@@ -564,7 +594,7 @@ constexpr size_t kCounterWords = (size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE;
 // Queues one render (counter reset, optional tile-order probe, frame launch) on `st`; nothing here waits.
 int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
                    uint32_t flags, void* d_rgb, void* d_hit, hipStream_t st, rtx_ctx::Lane* lane,
-                   unsigned long long* d_counters, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                   unsigned long long* d_counters, hipEvent_t ev_begin, hipEvent_t ev_end, bool may_allocate = true) {
     if (!ctx || !scene || !cam || !d_rgb) return RTX_E_INVALID;
     if (scene->ctx != ctx) return fail(ctx, RTX_E_INVALID, "scene belongs to another context");
     if (cam->hsize <= 0 || cam->vsize <= 0) return fail(ctx, RTX_E_INVALID, "empty camera");
@@ -589,14 +619,14 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     {
         // a multiplier coprime with the tile count (default 7919; RTX_TILE_MUL overrides for experiments)
         const long long n_tiles = (long long)rp.tiles_x * rp.n_bands_local;
-        const char* e = getenv("RTX_TILE_MUL");
-        long long m = e ? atoll(e) : 7919;
+        long long m = ctx->opt.tile_mul;
         auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
         if (m < 1) m = 1;
         while (n_tiles > 1 && gcd(m % n_tiles ? m % n_tiles : n_tiles, n_tiles) != 1) m++;
         rp.tile_mul = (int)(n_tiles > 0 ? m % (n_tiles > 1 ? n_tiles : 2) : 1);
         if (rp.tile_mul == 0) rp.tile_mul = 1;
     }
+    rp.sticky = ctx->d_sticky;
     rp.compact = (flags & RTX_F_BANDS_COMPACT) ? 1 : 0;
     rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
 
@@ -611,10 +641,10 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     // then varies by two orders of magnitude) and the dispatch is long; RTX_LPT=0/1 overrides.
     {
         const int n_tiles = rp.tiles_x * rp.n_bands_local;
-        const char* e = getenv("RTX_LPT");
-        const bool want = e ? atoi(e) != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching);
+        const bool want = ctx->opt.lpt >= 0 ? ctx->opt.lpt != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching);
         if (want && n_tiles > 0) {
             if (lane->tile_cap < (size_t)n_tiles) {
+                if (!may_allocate) return fail(ctx, RTX_E_CAPACITY, "frame has more tiles than the no-alloc scratch holds");
                 if (lane->d_lists) (void)hipFree(lane->d_lists);
                 lane->d_lists = nullptr; lane->tile_cap = 0;
                 HIPCHK(ctx, hipMalloc((void**)&lane->d_lists, (size_t)RTX_TILE_CLASSES * n_tiles * sizeof(int32_t)));
@@ -630,30 +660,29 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 pp.super_mul = (int)(n_super > 1 ? m % n_super : 1);
                 if (pp.super_mul == 0) pp.super_mul = 1;
             }
-            pp.probe = 1; pp.max_depth = getenv("RTX_PROBE_DEPTH") ? atoi(getenv("RTX_PROBE_DEPTH")) : 2;   // (1, 2, 3 measured: 2 is best)
+            pp.probe = 1; pp.max_depth = ctx->opt.probe_depth;   // (1, 2, 3 measured: 2 is best)
+            if (pp.max_depth < 0) pp.max_depth = 0;
             if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lane->d_lists; pp.tile_counts = lane->d_tile_counts;
             HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, st));
             rp.use_lists = 1; rp.tile_lists = lane->d_lists; rp.tile_counts = lane->d_tile_counts;
             // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
             // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
             // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
-            const char* se = getenv("RTX_SPLIT");
-            const bool split = se ? atoi(se) != 0 : n_tiles <= RTX_SPLIT_MAX_TILES;
-            if (split) {
+            const bool split = ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES;
+            if (split && lane->side) {
                 rp.split_cap = n_tiles / 4 > 0 ? n_tiles / 4 : 1;
-                rp.split_min_class = getenv("RTX_SPLIT_CLASS") ? atoi(getenv("RTX_SPLIT_CLASS")) : 6;
+                rp.split_min_class = ctx->opt.split_class;
                 if (rp.split_min_class < 1) rp.split_min_class = 1;
+                // a wave of the SPLIT kernel whose lanes wait for each other must still end; one pixel's own chain is at most
+                // (2^(d+1) - 1) * (1 + n_lights) traces, the bound leaves 4x room on top of 16 pixels per wave
+                const long long g = 4ll * 16 * (2ll << max_depth) * (1 + scene->dev.n_lights);
+                rp.split_guard = (int32_t)(g > 0x3fffffff ? 0x3fffffff : g);
             }
         }
     }
     if (rp.split_cap > 0) {
         // fork: the SPLIT launch (expensive tiles, several waves each) goes first, on the lane's side stream; the
         // main launch renders the other tiles beside it and waits for it at the end
-        if (!lane->side) {
-            HIPCHK(ctx, hipStreamCreateWithFlags(&lane->side, hipStreamNonBlocking));
-            HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_fork, hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_join, hipEventDisableTiming));
-        }
         HIPCHK(ctx, hipEventRecord(lane->ev_fork, st));
         HIPCHK(ctx, hipStreamWaitEvent(lane->side, lane->ev_fork, 0));
         RenderParams sp = rp; sp.split_launch = 1;
@@ -665,6 +694,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                                        (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, st));
     if (rp.split_cap > 0) HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_join, 0));
     if (ev_end) HIPCHK(ctx, hipEventRecord(ev_end, st));
+    ctx->last_stream = st;
     return RTX_OK;
 }
 
@@ -685,30 +715,47 @@ int fill_stats(rtx_ctx* ctx, const rtx_camera* cam, rtx_bands bands, const unsig
     stats->rays_primary = prim;
     stats->rays_secondary = h[RTX_CNT_RADIANCE] - prim;
     stats->rays_shadow = h[RTX_CNT_SHADOW];
-    stats->overflow_pixels = h[RTX_CNT_OVERFLOW];
+    stats->overflow_pixels = h[RTX_CNT_OVERFLOW] % RTX_GUARD_UNIT;
     for (int i = 0; i < RTX_EV_COUNT; i++) stats->ev[i] = h[RTX_CNT_EV0 + i];
     stats->kernel_ms = ms;
+    if (h[RTX_CNT_OVERFLOW] >= RTX_GUARD_UNIT)
+        return fail(ctx, RTX_E_CAPACITY, "a split-tile wave exceeded its iteration guard (pixels of that tile are unwritten)");
     if (stats->overflow_pixels) return fail(ctx, RTX_E_CAPACITY, "bounded CSG list overflowed on the device");
     return RTX_OK;
 }
 
 }  // namespace
 
+int rtx_check_sticky(rtx_ctx* ctx) {
+    if (ctx->h_sticky && *ctx->h_sticky != 0)
+        return rtx_fail(ctx, RTX_E_CAPACITY, "an earlier asynchronous render overflowed a bounded list or tripped the split guard "
+                                             "(its image is incomplete); rtx_ctx_poll() clears the condition");
+    return RTX_OK;
+}
+
+int rtx_enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+                       uint32_t flags, void* d_rgb, void* d_hit, hipStream_t st, rtx_ctx::Lane* lane,
+                       unsigned long long* d_counters, hipEvent_t ev_begin, hipEvent_t ev_end, bool may_allocate) {
+    return enqueue_render(ctx, scene, cam, max_depth, bands, flags, d_rgb, d_hit, st, lane, d_counters, ev_begin, ev_end, may_allocate);
+}
+
 extern "C" {
 
 int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
                       uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats) {
     if (!ctx) return RTX_E_INVALID;
+    int rc = rtx_check_sticky(ctx);               // an earlier asynchronous render overflowed and nobody collected it
+    if (rc != RTX_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    int rc = enqueue_render(ctx, scene, cam, max_depth, bands, flags, d_rgb, d_hit, st, &ctx->lanes[0], ctx->d_counters,
-                            stats ? ctx->ev0 : nullptr, stats ? ctx->ev1 : nullptr);
+    rc = enqueue_render(ctx, scene, cam, max_depth, bands, flags, d_rgb, d_hit, st, &ctx->lanes[0], ctx->d_counters,
+                        stats ? ctx->ev0 : nullptr, stats ? ctx->ev1 : nullptr);
     if (rc != RTX_OK || !stats) return rc;
-    std::vector<unsigned long long> rep(kCounterWords);
-    HIPCHK(ctx, hipMemcpyAsync(rep.data(), ctx->d_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    return fill_stats(ctx, cam, bands, rep.data(), ms, stats);
+    *ctx->h_sticky = 0;                           // this call reports its own overflow through the return code
+    return fill_stats(ctx, cam, bands, ctx->h_counters, ms, stats);
 }
 
 int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
@@ -808,6 +855,11 @@ int rtx_render_batch(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam
         rtx_ctx::Lane& ln = ctx->lanes[l];
         if (!ln.stream) HIPCHK(ctx, hipStreamCreate(&ln.stream));
         if (!ln.d_tile_counts) HIPCHK(ctx, hipMalloc((void**)&ln.d_tile_counts, 64 * sizeof(int32_t)));
+        if (!ln.side) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+        }
         if (scene->dev.has_branching && ln.tile_cap < max_tiles) {           // grow now: hipFree would stall the queue later
             if (ln.d_lists) (void)hipFree(ln.d_lists);
             ln.d_lists = nullptr; ln.tile_cap = 0;
@@ -859,6 +911,9 @@ int rtx_render_batch(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam
         }
     }
     drop_events();
+    // (frames without stats: an overflow shows up in the sticky word the launches set; every lane is drained here)
+    if (rc == RTX_OK) rc = rtx_check_sticky(ctx);
+    *ctx->h_sticky = 0;
     return rc;
 }
 

@@ -155,6 +155,8 @@ struct RenderParams {
     int32_t probe, use_lists;  // probe: this IS the probe launch (no image, no counters); use_lists: follow the lists
     int32_t split_launch;     // this IS the SPLIT launch (the expensive tiles, several waves per tile)
     int32_t split_min_class;  // SPLIT kernels: tiles of this class and above are split (up to split_cap tiles)
+    int32_t split_guard;      // SPLIT kernels: wave iterations after which a wave gives up (a hung wave hangs the GPU); from max_depth and n_lights
+    unsigned long long* sticky;   // device-visible host word: set non-zero when this launch reports an overflow (asynchronous renders)
     int32_t tile_mul;         // block b renders tile (b * tile_mul) mod n_tiles: coprime with n_tiles, spreads heavy image
                               //   regions over the whole dispatch instead of leaving them to the tail
 };
@@ -174,6 +176,7 @@ struct RenderParams {
 #define RTX_SPLIT_MAX_TILES 20000   /* launches of at most this many tiles split their most expensive tiles over several waves */
 #endif
 #define RTX_CNT_SLOTS 256
+#define RTX_GUARD_UNIT (1ull << 32)   /* the overflow counter's high half counts waves that tripped the SPLIT guard */
 #define RTX_CNT_STRIDE 32
 
 #endif

@@ -1,0 +1,82 @@
+// rtx_internal.h — host-side state behind the opaque handles of include/rtx.h, shared by
+// rtx_api.hip (scene compiler, single-GPU entry points) and rtx_multi.hip (RCCL band gather).
+#ifndef RTX_INTERNAL_H
+#define RTX_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+
+// scheduling knobs: read from the environment ONCE, at rtx_init; rtx_set_option() changes them per context
+struct rtx_opts {
+    int lpt = -1;            // expensive-tiles-first order: -1 = per-scene default, 0 / 1 = forced
+    int tile_mul = 7919;     // multiplier of the tile permutation
+    int probe_depth = 2;     // depth budget of the tile-cost probe launch
+    int split = -1;          // split tiles: -1 = default (short dispatches), 0 / 1 = forced
+    int split_class = 6;     // tiles of this cost class and above are split
+    int debug = 0;
+};
+
+struct rtx_scene;
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* d_counters = nullptr;
+    // scheduling state of one stream: tile class lists (grown on demand) and their fill counts.  lanes[0] runs
+    // on `stream`; lanes 1.. have streams of their own and are created by the first rtx_render_batch.
+    // side/ev_fork/ev_join: the SPLIT launch of a frame runs on `side`, beside the main launch
+    struct Lane { hipStream_t stream = nullptr; int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0;
+                  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    static constexpr int kLanes = 4;
+    Lane lanes[kLanes];
+    uint8_t* h_stage = nullptr; size_t stage_cap = 0;                        // pinned staging of a batch's images
+    uint8_t* d_rgb = nullptr; size_t rgb_cap = 0;
+    int32_t* d_hit = nullptr; size_t hit_cap = 0;
+    unsigned long long* d_batch_counters = nullptr; size_t batch_cap = 0;   // one counter block per frame of a batch
+    unsigned long long* h_counters = nullptr;                               // pinned copy of one counter block (stats path)
+    // sticky error word of asynchronous renders: pinned host memory the device can write (rtx_kernel.hip stores the
+    // overflow count's "non-zero" there); read by the next render call / rtx_ctx_poll without touching the stream
+    volatile unsigned long long* h_sticky = nullptr;
+    unsigned long long* d_sticky = nullptr;                                  // the same word as the device addresses it
+    hipStream_t last_stream = nullptr;                                       // stream of the last queued render (rtx_ctx_poll waits on it)
+    // the library's no-alloc scratch (rtx_api.hip: `scratch`): this device's copy of the file-scope array
+    unsigned char* d_scratch = nullptr;
+    Lane noalloc_lane;                                                       // lists / counts inside d_scratch, side stream shared with lanes[0]
+    rtx_opts opt;
+    std::vector<rtx_scene*> scenes;                                          // live scenes (rtx_shutdown releases their device memory)
+    std::string err;
+};
+
+struct rtx_scene {
+    rtx_ctx* ctx = nullptr;      // nullptr once the context is gone (rtx_shutdown released the device memory)
+    int device = 0;
+    SceneDev dev{};
+    void* d_ops = nullptr; void* d_bodies = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
+    void* d_materials = nullptr; void* d_lights = nullptr; void* d_pairs = nullptr;
+    void* d_chunks = nullptr; void* d_counts = nullptr; void* d_lcull = nullptr; void* d_lops = nullptr; void* d_conts = nullptr;
+};
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            return RTX_E_DEVICE;                                                       \
+        }                                                                              \
+    } while (0)
+
+static inline int rtx_fail(rtx_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+// rtx_api.hip: queues one render (counter reset, optional tile-order probe, frame launch) on `st`; nothing waits.
+int rtx_enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+                       uint32_t flags, void* d_rgb, void* d_hit, hipStream_t st, rtx_ctx::Lane* lane,
+                       unsigned long long* d_counters, hipEvent_t ev_begin, hipEvent_t ev_end, bool may_allocate);
+// RTX_E_CAPACITY (and the message) if an earlier asynchronous render reported an overflow that nobody collected yet
+int rtx_check_sticky(rtx_ctx* ctx);
+
+#endif

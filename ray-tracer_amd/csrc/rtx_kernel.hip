@@ -431,16 +431,18 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
 
+    bool guard_hit = false;
     int guard = 0;                        // SPLIT: a wave whose lanes wait for each other must still end (it cannot happen by
                                           // construction — helpers never wait for their owners — but a hung wave hangs the GPU)
     while (__any(mode != MODE_DONE || (SPLIT && waiting))) {
-        if (SPLIT && ++guard > 64 * (2 << RTX_MAX_DEPTH)) { if (lane == 0) overflow++; break; }
+        if (SPLIT && ++guard > rp.split_guard) { guard_hit = true; break; }
         TM(tm_shade);
         // ================================================================= TRACE
         // World::intersect (world.rs:111-118) for every lane's current ray.
 #ifdef RTX_WAVE_TRACE
         wt_iters += (mode != MODE_DONE) ? 1 : 0;
 #endif
+        if (SPLIT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // a donor lane may have written this lane's ray slot
         if (mode == MODE_RADIANCE) n_radiance++;
         else if (mode == MODE_SHADOW) n_shadow++;
         EV(RTX_EV_LANE_SLOTS, 1);         // every lane, busy or not: 64 per wave trace
@@ -1162,6 +1164,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         double* hs = lds_rays + target;            // the helper's ray slot 0
                         hs[0] = f.o2[0]; hs[64] = f.o2[1]; hs[128] = f.o2[2]; hs[192] = f.d2[0]; hs[256] = f.d2[1]; hs[320] = f.d2[2];
                         mb_rem[target] = f.remaining - 1;
+                        // (the helper reads its ray slot with plain loads: order the stores above before the flag, and see
+                        // the acquire fence at the top of the trace)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         mb_state[target] = 1;
                         f.flags = (f.flags & ~FR_REFR_PENDING) | FR_REMOTE | (target << FR_HELPER_SHIFT);
                     }
@@ -1320,7 +1325,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     if (lane == 0) {
         atomicAdd(&counters[RTX_CNT_RADIANCE], (unsigned long long)t0);
         atomicAdd(&counters[RTX_CNT_SHADOW], (unsigned long long)t1);
-        if (t2) atomicAdd(&counters[RTX_CNT_OVERFLOW], (unsigned long long)t2);
+        if (t2 || guard_hit) {
+            // never silently truncated: the count goes to the counters (synchronous renders read them) and the
+            // context's sticky host word is raised (asynchronous renders: checked by the next call / rtx_ctx_poll)
+            atomicAdd(&counters[RTX_CNT_OVERFLOW], (unsigned long long)t2 + (guard_hit ? RTX_GUARD_UNIT : 0ull));
+            if (rp.sticky) __hip_atomic_store(rp.sticky, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (COUNT) {
 #pragma unroll

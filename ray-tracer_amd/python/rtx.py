@@ -67,7 +67,8 @@ class SceneDesc(C.Structure):
 
 # every symbol include/rtx.h and include/rtx_host.h declare
 RTX_SYMBOLS = ["rtx_init", "rtx_shutdown", "rtx_scene_create", "rtx_scene_destroy", "rtx_render",
-               "rtx_render_device", "rtx_render_batch", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
+               "rtx_render_device", "rtx_ctx_poll", "rtx_set_option",
+               "rtx_render_batch", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
 RTXH_SYMBOLS = ["rtxh_identity", "rtxh_translation", "rtxh_scaling", "rtxh_rotation_x", "rtxh_rotation_y",
                 "rtxh_rotation_z", "rtxh_view_transform", "rtxh_mat_mul", "rtxh_inverse",
                 "rtxh_default_material", "rtxh_world_new", "rtxh_world_free", "rtxh_add_shape",
@@ -91,6 +92,7 @@ def _load():
         "rtx_scene_destroy": (None, [vp]),
         "rtx_render": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, pu8, pi32, C.POINTER(Stats)]),
         "rtx_render_device": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, vp, vp, vp, C.POINTER(Stats)]),
+        "rtx_ctx_poll": (i, [vp, i]), "rtx_set_option": (i, [vp, C.c_char_p, i]),
         "rtx_render_batch": (i, [vp, vp, C.POINTER(RtxCamera), i, i, u32, C.POINTER(pu8), C.POINTER(pi32), C.POINTER(Stats)]),
         "rtx_band_rows": (i, [i, Bands]),
         "rtx_debug_math": (i, [vp, i, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -141,6 +143,18 @@ class Context:
 
     def scene(self, world):
         return Scene(self, world)
+
+    def set_option(self, name, value):
+        """rtx_set_option: scheduling knobs ("lpt", "split", "split_class", "tile_mul", "probe_depth"); -1 = default."""
+        self._check(LIB.rtx_set_option(self.h, name.encode(), int(value)))
+
+    def options(self, **kv):
+        for k, v in kv.items():
+            self.set_option(k, v)
+
+    def poll(self, wait=True):
+        """rtx_ctx_poll: raises RtxError(E_CAPACITY) if an asynchronous render overflowed; clears the condition."""
+        self._check(LIB.rtx_ctx_poll(self.h, 1 if wait else 0))
 
     def debug_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, np.float64)

@@ -200,9 +200,9 @@ def test_tile_order_does_not_change_the_image(ctx, monkeypatch):
     pw, pc = rtx.load_yaml(text)
     sc = ctx.scene(pw)
     try:
-        monkeypatch.setenv("RTX_LPT", "0")
+        ctx.set_option("lpt", 0)
         a = sc.render(pc[0], 5)
-        monkeypatch.setenv("RTX_LPT", "1")
+        ctx.set_option("lpt", 1)
         b = sc.render(pc[0], 5)
         assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"])
         assert a["stats"].rays == b["stats"].rays
@@ -211,6 +211,7 @@ def test_tile_order_does_not_change_the_image(ctx, monkeypatch):
             sc.render(pc[0], 5, bands=(g, 3), out=(rgb, hit))
         assert np.array_equal(rgb, a["rgb"]) and np.array_equal(hit, a["hit"])
     finally:
+        ctx.set_option("lpt", -1)
         sc.close()
 
 
@@ -234,7 +235,7 @@ def test_batch_of_cameras_equals_single_renders(ctx, monkeypatch):
     assert len(pcs) == 4
     sc = ctx.scene(pw)
     try:
-        monkeypatch.setenv("RTX_LPT", "1")                       # the probe and its lists are shared by the queued frames
+        ctx.set_option("lpt", 1)                                 # the probe and its lists are shared by the queued frames
         batch = sc.render_batch(pcs, 5, flags=rtx.F_COUNT_EVENTS)
         for k, cam in enumerate(pcs):
             one = sc.render(cam, 5, flags=rtx.F_COUNT_EVENTS)
@@ -245,13 +246,14 @@ def test_batch_of_cameras_equals_single_renders(ctx, monkeypatch):
             be, oe = bs.events(), os_.events()
             assert {k: v for k, v in be.items() if k not in ("lane_slots", "op_slots")} == \
                 {k: v for k, v in oe.items() if k not in ("lane_slots", "op_slots")} and bs.kernel_ms > 0
-        monkeypatch.delenv("RTX_LPT")
+        ctx.set_option("lpt", -1)
         plain = sc.render_batch(pcs, 5, want_hit=False, want_stats=False)
         assert all(np.array_equal(plain[k]["rgb"], batch[k]["rgb"]) for k in range(4))
         assert sc.render_batch([], 5) == []
         with pytest.raises(rtx.RtxError):
             sc.render_batch(pcs, 5, flags=rtx.F_BANDS_COMPACT)
     finally:
+        ctx.set_option("lpt", -1)
         sc.close()
     (_, _), (ow, oc) = parity.build_both(parity.scene_text("S4", 160, 96))
     cpu = ora.render(ow, oc, 5, threads=8)
@@ -288,13 +290,11 @@ def test_split_tiles_do_not_change_the_image(ctx, monkeypatch, name, w, h):
     pw, pc = rtx.load_yaml(text)
     sc = ctx.scene(pw)
     try:
-        monkeypatch.setenv("RTX_LPT", "1")
-        monkeypatch.setenv("RTX_SPLIT", "0")
+        ctx.options(lpt=1, split=0)
         a = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
-        monkeypatch.setenv("RTX_SPLIT", "1")
-        monkeypatch.setenv("RTX_SPLIT_CLASS", "4")
+        ctx.options(split=1, split_class=4)
         b = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
-        monkeypatch.delenv("RTX_SPLIT_CLASS")
+        ctx.set_option("split_class", 6)
         c = sc.render(pc[0], 5)
         for r in (b, c):
             assert np.array_equal(a["rgb"], r["rgb"]) and np.array_equal(a["hit"], r["hit"])
@@ -307,6 +307,7 @@ def test_split_tiles_do_not_change_the_image(ctx, monkeypatch, name, w, h):
             sc.render(pc[0], 5, bands=(g, 3), out=(rgb, hit))
         assert np.array_equal(rgb, a["rgb"]) and np.array_equal(hit, a["hit"])
     finally:
+        ctx.options(lpt=-1, split=-1, split_class=6)
         sc.close()
 
 
@@ -317,17 +318,19 @@ def test_split_tiles_on_the_torture_scene(ctx, monkeypatch):
     import rtx
     import torture
     pw, pc = torture.build(rtx.API)
-    monkeypatch.setenv("RTX_LPT", "1")
-    monkeypatch.setenv("RTX_SPLIT", "0")
-    a = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS)
-    monkeypatch.setenv("RTX_SPLIT", "1")
-    for cls in ("1", "4", "6"):
-        monkeypatch.setenv("RTX_SPLIT_CLASS", cls)
-        b = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS)
-        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"]), cls
-        assert a["stats"].rays == b["stats"].rays
-        ea, eb = a["stats"].events(), b["stats"].events()
-        assert {k: ea[k] for k in rtapi.REF_EVENTS} == {k: eb[k] for k in rtapi.REF_EVENTS}, cls
+    try:
+        ctx.options(lpt=1, split=0)
+        a = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS)
+        ctx.set_option("split", 1)
+        for cls in (1, 4, 6):
+            ctx.set_option("split_class", cls)
+            b = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS)
+            assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"]), cls
+            assert a["stats"].rays == b["stats"].rays
+            ea, eb = a["stats"].events(), b["stats"].events()
+            assert {k: ea[k] for k in rtapi.REF_EVENTS} == {k: eb[k] for k in rtapi.REF_EVENTS}, cls
+    finally:
+        ctx.options(lpt=-1, split=-1, split_class=6)
 
 
 def test_randomized_scene_files_parity(ctx):

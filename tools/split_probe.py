@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Split tiles (RTX_SPLIT / RTX_SPLIT_CLASS, read at every render): kernel ms of one rank's share of the 4K frame
+"""Split tiles (context options "split" / "split_class"): kernel ms of one rank's share of the 4K frame
 for N = 1, 2, 4, 8 and of smaller whole frames, unsplit against splitting classes >= 7, 6, 5, 4."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,11 +14,11 @@ def best(sc, cam, bands, reps=5):
 
 
 def row(sc, cam, bands):
-    os.environ["RTX_SPLIT"] = "0"
+    ctx.set_option("split", 0)
     out = ["unsplit %.3f" % best(sc, cam, bands)]
-    os.environ["RTX_SPLIT"] = "1"
+    ctx.set_option("split", 1)
     for c in CLS:
-        os.environ["RTX_SPLIT_CLASS"] = c
+        ctx.set_option("split_class", int(c))
         out.append("%s %.3f" % (c, best(sc, cam, bands)))
     return "  ".join(out)
 
