@@ -165,6 +165,19 @@ int  rtx_ctx_poll(rtx_ctx*, int wait);
  * No counterpart in the reference (it has no scheduler). */
 int  rtx_set_option(rtx_ctx*, const char* name, int value);
 
+/* rtx_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same kernels and same output as rtx_render_device, but
+ * the ray counters and the tile-order lists live in a file-scope device array of the library (one copy per GPU,
+ * RTX_NOALLOC_SCRATCH: 64 KiB counters + 8 x RTX_NOALLOC_MAX_TILES x 4 B lists, about 4.1 MiB, held until the process
+ * ends) instead of hipMalloc'ed buffers, and the call allocates nothing (no hipMalloc / hipFree / stream or event
+ * creation: those happen in rtx_init).  Limit: launches of more than RTX_NOALLOC_MAX_TILES 8x8 tiles (a 4K frame is
+ * 129 600) are rejected with RTX_E_CAPACITY.  No stats; errors are sticky (rtx_ctx_poll).  All calls a process makes
+ * on one GPU share that GPU's array, which keeps the last call's contents (the call clears what must start at zero):
+ * calls that overlap on one GPU - two streams, two contexts - race on it; queue them on one stream. */
+#define RTX_NOALLOC_MAX_TILES 131072
+int  rtx_render_device_noalloc(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
+                               uint32_t flags, void* d_rgb, void* d_hit, void* stream);
+
 /* SURVEY.md §8f N4 — several frames of ONE resident scene: all cameras of a scene file (yaml.rs:34 parses
  * every `add: camera`, main.rs:24 renders only cameras[0]) or an animation sweep.  Every frame's launches are
  * queued back to back on the context's stream, the host waits once, then copies each image out: no per-frame

@@ -40,6 +40,16 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
     out[i] = r;
 }
 
+// ---- the library's no-alloc scratch (rtx_render_device_noalloc): counters + tile-order lists of ONE render in a
+// file-scope device array, so that entry point never calls hipMalloc.  Every GPU the library runs on holds its own
+// copy at its own address: rtx_init() asks for it with hipGetSymbolAddress and keeps the pointer in the context
+// (host code must never pass the array's NAME to a kernel or a memset: on the host it is only a stand-in).
+#define RTX_NOALLOC_COUNTER_BYTES ((size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long))   /* 64 KiB */
+#define RTX_NOALLOC_COUNTS_BYTES  256                                                                    /* tile_counts */
+#define RTX_NOALLOC_LISTS_BYTES   ((size_t)RTX_TILE_CLASSES * RTX_NOALLOC_MAX_TILES * sizeof(int32_t))    /* 4 MiB */
+#define RTX_NOALLOC_SCRATCH_BYTES (RTX_NOALLOC_COUNTER_BYTES + RTX_NOALLOC_COUNTS_BYTES + RTX_NOALLOC_LISTS_BYTES)
+static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 int fail(rtx_ctx* c, int code, const std::string& msg) { return rtx_fail(c, code, msg); }
@@ -361,6 +371,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.debug = env_int("RTX_DEBUG", 0);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
+    void* scratch_dev = nullptr;
     const bool ok =
         hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
         hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
@@ -372,14 +383,22 @@ int rtx_init(int device, rtx_ctx** out) {
         hipEventCreateWithFlags(&l0.ev_join, hipEventDisableTiming) == hipSuccess &&
         hipHostMalloc((void**)&c->h_counters, RTX_CNT_SLOTS * RTX_CNT_STRIDE * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
         hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-        hipHostGetDevicePointer(&sticky_dev, (void*)c->h_sticky, 0) == hipSuccess;
+        hipHostGetDevicePointer(&sticky_dev, (void*)c->h_sticky, 0) == hipSuccess &&
+        // this device's copy of the no-alloc scratch array (each GPU has its own, at its own address)
+        hipGetSymbolAddress(&scratch_dev, HIP_SYMBOL(scratch)) == hipSuccess && scratch_dev != nullptr;
     if (!ok) {
         rtx_shutdown(c);
         return RTX_E_DEVICE;
     }
     *c->h_sticky = 0;
     c->d_sticky = (unsigned long long*)sticky_dev;
+    c->d_scratch = (unsigned char*)scratch_dev;
     l0.stream = c->stream;
+    // the no-alloc lane: counts and lists live inside the scratch array; the side stream is lanes[0]'s
+    c->noalloc_lane.d_tile_counts = (int32_t*)(c->d_scratch + RTX_NOALLOC_COUNTER_BYTES);
+    c->noalloc_lane.d_lists = (int32_t*)(c->d_scratch + RTX_NOALLOC_COUNTER_BYTES + RTX_NOALLOC_COUNTS_BYTES);
+    c->noalloc_lane.tile_cap = RTX_NOALLOC_MAX_TILES;
+    c->noalloc_lane.side = l0.side; c->noalloc_lane.ev_fork = l0.ev_fork; c->noalloc_lane.ev_join = l0.ev_join;
     *out = c;
     return RTX_OK;
 }
@@ -756,6 +775,24 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ctx->h_sticky = 0;                           // this call reports its own overflow through the return code
     return fill_stats(ctx, cam, bands, ctx->h_counters, ms, stats);
+}
+
+int rtx_render_device_noalloc(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
+                              uint32_t flags, void* d_rgb, void* d_hit, void* stream) {
+    if (!ctx || !cam) return RTX_E_INVALID;
+    int rc = rtx_check_sticky(ctx);
+    if (rc != RTX_OK) return rc;
+    if (cam->hsize <= 0 || cam->vsize <= 0) return fail(ctx, RTX_E_INVALID, "empty camera");
+    if (bands.first < 0 || bands.stride < 1) return fail(ctx, RTX_E_INVALID, "bad band selection");
+    const long long n_tiles = (long long)((cam->hsize + RTX_TILE - 1) / RTX_TILE) * local_bands(cam->vsize, bands);
+    if (n_tiles > RTX_NOALLOC_MAX_TILES)
+        return fail(ctx, RTX_E_CAPACITY, "rtx_render_device_noalloc: " + std::to_string(n_tiles) + " tiles in this launch > RTX_NOALLOC_MAX_TILES (" +
+                                         std::to_string(RTX_NOALLOC_MAX_TILES) + "): render fewer bands per call or use rtx_render_device");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // counters, tile counts and tile lists all live in this device's copy of `scratch` (ctx->d_scratch, from
+    // hipGetSymbolAddress at rtx_init); enqueue_render clears what must start at zero on `st` before the launches
+    return enqueue_render(ctx, scene, cam, max_depth, bands, flags, d_rgb, d_hit, st, &ctx->noalloc_lane,
+                          (unsigned long long*)ctx->d_scratch, nullptr, nullptr, /*may_allocate=*/false);
 }
 
 int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,

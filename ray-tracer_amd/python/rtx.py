@@ -67,7 +67,7 @@ class SceneDesc(C.Structure):
 
 # every symbol include/rtx.h and include/rtx_host.h declare
 RTX_SYMBOLS = ["rtx_init", "rtx_shutdown", "rtx_scene_create", "rtx_scene_destroy", "rtx_render",
-               "rtx_render_device", "rtx_ctx_poll", "rtx_set_option",
+               "rtx_render_device", "rtx_render_device_noalloc", "rtx_ctx_poll", "rtx_set_option",
                "rtx_render_batch", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
 RTXH_SYMBOLS = ["rtxh_identity", "rtxh_translation", "rtxh_scaling", "rtxh_rotation_x", "rtxh_rotation_y",
                 "rtxh_rotation_z", "rtxh_view_transform", "rtxh_mat_mul", "rtxh_inverse",
@@ -92,6 +92,7 @@ def _load():
         "rtx_scene_destroy": (None, [vp]),
         "rtx_render": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, pu8, pi32, C.POINTER(Stats)]),
         "rtx_render_device": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, vp, vp, vp, C.POINTER(Stats)]),
+        "rtx_render_device_noalloc": (i, [vp, vp, C.POINTER(RtxCamera), i, Bands, u32, vp, vp, vp]),
         "rtx_ctx_poll": (i, [vp, i]), "rtx_set_option": (i, [vp, C.c_char_p, i]),
         "rtx_render_batch": (i, [vp, vp, C.POINTER(RtxCamera), i, i, u32, C.POINTER(pu8), C.POINTER(pi32), C.POINTER(Stats)]),
         "rtx_band_rows": (i, [i, Bands]),
@@ -232,6 +233,14 @@ class Scene:
         st = (Stats * n)() if want_stats else None
         self.ctx._check(LIB.rtx_render_batch(self.ctx.h, self.h, flat, n, max_depth, flags, prgb, phit, st))
         return [dict(rgb=rgb[k], hit=hit[k] if want_hit else None, stats=st[k] if want_stats else None) for k in range(n)]
+
+    def render_device_noalloc(self, cam, d_rgb, d_hit=0, max_depth=5, bands=(0, 1), flags=0, stream=0):
+        """rtx_render_device_noalloc: same output, counters and tile lists in the library's static scratch array."""
+        fc = self.flat_camera(cam)
+        rc = LIB.rtx_render_device_noalloc(self.ctx.h, self.h, C.byref(fc), max_depth, Bands(*bands), flags,
+                                           C.c_void_p(d_rgb), C.c_void_p(d_hit) if d_hit else None,
+                                           C.c_void_p(stream) if stream else None)
+        self.ctx._check(rc)
 
     def render_device(self, cam, d_rgb, d_hit=0, max_depth=5, bands=(0, 1), flags=0, stream=0, stats=False):
         """rtx_render_device: outputs are device pointers (ints), e.g. torch tensor .data_ptr()."""
