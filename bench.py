@@ -2,19 +2,28 @@
 """bench.py — Mrays/s (primary + shadow + secondary) of the MI355X trace-and-shade path.
 
 A "step" is one frame: every rank renders its row-interleaved 8-row tile bands of the SAME frame
-(rank r gets bands r, r+N, ...) with the scene resident in HBM, then the bands are all-gathered
-over RCCL (N > 1).  Total work per step is fixed as N grows -> "strong" scaling; value = whole-job
-rays per second.  Launched by the driver as `python bench.py --gpus 1 ...` or, for N > 1, through
-torch.distributed.run (one process per GPU).
+(rank r gets bands r, r+N, ...) with the scene resident in HBM; for N > 1 the bands are all-gathered
+and de-interleaved INSIDE the product (rtx_render_gathered in include/rtx.h: one ncclAllGather over
+RCCL/xGMI on the library's own stream, overlapped with the next frame's render).  Total work per step
+is fixed as N grows -> "strong" scaling; value = whole-job rays per second.
 
-Extra objects on the JSON line: `roofline` (FP64 vector ALU bound: algorithmic flops of the frame
-from the kernel's own event counters / the kernel's measured launch time) and `cpu_baseline` (the
-CPU oracle — a C++ restatement of the single-threaded reference, `kind: "port"` — timed on a
-bounded tile sample of the same frame on this box's host cores, rank 0, N = 1 only).
+Launch: `python bench.py --gpus N ...`.  For N > 1 without a torch.distributed environment the script
+starts its N ranks itself (a child `python -m torch.distributed.run`, before anything touches the
+GPU) and forwards the exit code; under torch.distributed.run it is one of the ranks.
+
+Extra objects on the JSON line: `roofline` (FP64 vector ALU bound: algorithmic flops of the frame from
+the kernel's own event counters / the kernel's launch time measured with HIP events on the launch
+stream; `valu_issue_frac`, `resident_waves` and `traffic` come from the rocprofv3 PMC passes recorded in
+profiles/<tag>_counters.json together with the git revision they were taken at), `cpu_baseline` (the
+CPU oracle — a C++ restatement of the single-threaded reference, `kind: "port"` — timed on a bounded
+tile sample of the same frame on this box's host cores, rank 0, N = 1 only) and `secondary` (the other
+3840x2160 configuration, S3, measured the same way in the same run).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -68,6 +77,21 @@ def cpu_baseline(text, width, height, budget_s=15.0):
             "ms_per_frame_extrapolated": secs * (width * height) / st.rays_primary * 1000.0}
 
 
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks (one process per GPU) as a child
+    `python -m torch.distributed.run` and return its exit code.  Nothing in THIS process has touched the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def len_lights(text):
+    return text.count("- add: light")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,193 +101,204 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py start them: "
+                         "run it without a torch.distributed environment)" % (args.gpus, world_size))
 
     import torch
-    import bands as bandlib
     import flops
     import rtx
     import scenes
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (e.g. 2 ranks, gloo, one GPU):
-    # RTX_BENCH_BACKEND=gloo maps every rank onto the GPUs that exist.  The driver's runs never set it.
+    # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (2 ranks, gloo, one GPU):
+    # RTX_BENCH_BACKEND=gloo maps every rank onto the GPUs that exist and gathers through host memory + the C ABI's host
+    # de-interleave, because RCCL refuses two ranks on one device.  The driver's runs never set it.
     backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    N = args.gpus
+    N = world_size
     dist = None
-    if world_size > 1:
+    if N > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world_size)
-        N = world_size
+            dist.init_process_group(backend, rank=rank, world_size=N)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace-and-shade path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
-    # collectives: RCCL on device tensors; the gloo rehearsal stages through host memory
     def all_reduce(t, op=None):
         if backend == "nccl":
             dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
         else:
             c = t.cpu(); dist.all_reduce(c, op=op or dist.ReduceOp.SUM); t.copy_(c)
 
-    def all_gather(out, inp):
-        if backend == "nccl":
-            dist.all_gather_into_tensor(out, inp)
-        else:
-            parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(world_size)]
-            dist.all_gather(parts, inp.cpu()); out.copy_(torch.cat(parts))
-
-    class _Done:                     # stand-in for a finished collective (the gloo rehearsal gathers synchronously)
-        def wait(self):
-            return True
-
-    def all_gather_async(out, inp):
-        if backend == "nccl":
-            return dist.all_gather_into_tensor(out, inp, async_op=True)
-        all_gather(out, inp)
-        return _Done()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    scene_name, width, height, desc = WORKLOADS[args.workload]
-    width, height = args.width or width, args.height or height
-    text = scenes.make(scene_name, width=width, height=height)
-    world, cams = rtx.load_yaml(text)
-    cam = cams[0]
     ctx = rtx.Context(local_rank)
-    scene = ctx.scene(world)                      # scene resident in HBM from here on
-
-    bands = (rank, N)
-    rows_local = rtx.LIB.rtx_band_rows(height, rtx.Bands(*bands))
-    rows_pad = bandlib.rows_padded(height, N)                  # equal send counts for the all-gather
-    assert rows_local <= rows_pad
-    local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(N * rows_pad * width * 3, dtype=torch.uint8, device=dev) if N > 1 else None
-    # a real (non-null) stream for everything below: the kernel launches, the timing events and the streams RCCL
-    # synchronises with are then one and the same queue (the null stream would hand the C ABI its own stream)
+    # a real (non-null) stream for everything below: the kernel launches and the timing events are then one queue
     compute = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(compute)
     stream = compute.cuda_stream
 
-    def step(stats=False):
-        st = scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, stats)
+    # the product's communicator for the band gather (RCCL inside librtx_hip.so); torch.distributed only carries the 128-byte id,
+    # the barrier and the max-over-ranks of the timings
+    comm = None
+    if N > 1 and backend == "nccl":
+        idt = torch.zeros(rtx.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(rtx.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm = rtx.Comm(ctx, bytes(idt.cpu().numpy().tobytes()), rank, N)
+
+    def measure(workload, width, height, steps, warmup):
+        """-> dict of this workload's numbers (on every rank; only rank 0 prints)"""
+        scene_name, w0, h0, desc = WORKLOADS[workload]
+        width, height = width or w0, height or h0
+        text = scenes.make(scene_name, width=width, height=height)
+        world, cams = rtx.load_yaml(text)
+        cam = cams[0]
+        scene = ctx.scene(world)                      # scene resident in HBM from here on
+        bands = (rank, N)
+        rows_pad = rtx.LIB.rtx_band_rows_padded(height, N)
+        local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
+        frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=dev) for _ in range(2)] if N > 1 else None
+        gathered_host = torch.zeros((N, rows_pad * width * 3), dtype=torch.uint8) if (N > 1 and comm is None) else None
+
+        # exact ray and event counts of this rank's share (untimed); a device-side overflow would raise here
+        st = scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT | rtx.F_COUNT_EVENTS, stream, True)
+        assert st.overflow_pixels == 0
+        evs = st.events()
+        nl = len_lights(text)
+        counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_secondary,
+                               flops.frame_flops(evs, st.rays_primary, st.rays_shadow, nl),
+                               flops.executed_flops(evs, st.rays_primary, st.rays_shadow, nl),
+                               evs["cull"], evs["x_xform"], evs["xform"], evs["backface"]], dtype=torch.float64, device=dev)
         if N > 1:
-            all_gather(gathered, local)
-        return st
+            all_reduce(counts)
+        rays_frame = int(counts[0] + counts[1] + counts[2])
 
-    # exact ray and event counts of this rank's share (untimed)
-    st = scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT | rtx.F_COUNT_EVENTS, stream, True)
-    rays_local = st.rays
-    evs = st.events()
-    fl_local = flops.frame_flops(evs, st.rays_primary, st.rays_shadow, len_lights(text))
-    fl_exec = flops.executed_flops(evs, st.rays_primary, st.rays_shadow, len_lights(text))
-    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_secondary, fl_local, fl_exec,
-                           evs["cull"], evs["x_xform"], evs["xform"]], dtype=torch.float64, device=dev)
-    if N > 1:
-        all_reduce(counts)
-    rays_frame = int(counts[0] + counts[1] + counts[2])
+        def step(k):
+            if comm is not None:
+                comm.render_gathered(scene, cam, frames[k & 1].data_ptr(), 0, 5, 0, stream)
+            else:
+                scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
+                if N > 1:      # gloo rehearsal: host gather + the C ABI's host de-interleave
+                    torch.cuda.current_stream().synchronize()
+                    parts = [torch.empty_like(gathered_host[0]) for _ in range(N)]
+                    dist.all_gather(parts, local.cpu())
+                    rtx.band_deinterleave(torch.stack(parts).numpy(), N, width, height)
 
-    for _ in range(args.warmup):
-        step()
-    if N > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # N > 1 over RCCL: frame k's all-gather runs on RCCL's stream while frame k+1 renders on the compute stream
-    # (two band buffers, two frame buffers); a buffer is reused only after its own gather has been waited for.
-    overlap = N > 1 and os.environ.get("RTX_BENCH_OVERLAP", "1") != "0"
-    if overlap:
-        locals_ = [local, torch.zeros_like(local)]
-        frames_ = [gathered, torch.zeros_like(gathered)]
-        pending = [None, None]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if overlap:
-            b = k & 1
-            if pending[b] is not None:
-                pending[b].wait()                 # stream-level: the compute stream waits for that gather
-            ev[k][0].record()
-            scene.render_device(cam, locals_[b].data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
-            ev[k][1].record()
-            pending[b] = all_gather_async(frames_[b], locals_[b])
-            continue
-        ev[k][0].record()
-        scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
-        ev[k][1].record()
+        for k in range(warmup):
+            step(k)
+        if comm is not None:
+            comm.wait()
         if N > 1:
-            all_gather(gathered, local)
-    if overlap:
-        for w in pending:
-            if w is not None:
-                w.wait()
-    torch.cuda.synchronize()
-    if N > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / args.steps], dtype=torch.float64, device=dev)
-    if N > 1:
-        all_reduce(elapsed, dist.ReduceOp.MAX)
-        all_reduce(kern_ms, dist.ReduceOp.MAX)
-    elapsed = float(elapsed[0]); kern_ms = float(kern_ms[0])
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1000.0
-        # per launch (= per GPU): each rank's launch does 1/N of the frame's flops in kern_ms (slowest rank)
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if N == 1:
+                ev[k][0].record()
+            step(k)
+            if N == 1:
+                ev[k][1].record()
+        if comm is not None:
+            comm.wait()                               # host waits for the last gather + de-interleave (and polls the sticky error)
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        ctx.poll(wait=True)                           # an overflow in any timed frame is an error, not a number
+        if N == 1:
+            kern = sum(a.elapsed_time(b) for a, b in ev) / steps
+        else:
+            # per-rank kernel time of its share, from the library's own HIP events (3 synchronous renders after the timed region:
+            # inside it the render of frame k+1 overlaps the gather of frame k on another stream)
+            kern = min(scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, True).kernel_ms for _ in range(3))
+        t = torch.tensor([t1 - t0, kern], dtype=torch.float64, device=dev)
+        if N > 1:
+            all_reduce(t, dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+        scene.close()
+        full_size = (width, height) == (w0, h0)
+        pmc = flops.pmc_counters(workload) if (N == 1 and full_size) else None
         achieved = float(counts[3]) / N / (kern_ms / 1000.0) / 1e12
         executed = float(counts[4]) / N / (kern_ms / 1000.0) / 1e12
-        traffic = flops.measured_traffic_bytes(args.workload) if (N == 1 and not args.width and not args.height) else None
-        out = {
-            "metric": "Mrays/sec (primary+shadow+secondary)", "value": rays_frame * args.steps / elapsed / 1e6,
-            "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, desc), "width": width, "height": height,
-                       "max_depth": 5, "rays_per_frame": rays_frame,
-                       "rays": {"primary": int(counts[0]), "shadow": int(counts[1]), "secondary": int(counts[2])},
-                       "parallelism": ("row-interleaved 8-row bands x%d + RCCL all-gather%s" % (N, " overlapped with the next frame" if overlap else "")) if N > 1 else "1 GPU"},
-            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": flops.FP64_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS,
-                         "traffic": traffic[0] if traffic else None,
-                         "traffic_note": ("L2<->fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB units) from the committed "
-                                          "rocprofv3 --pmc passes profiles/r1f_S4_pmc.txt / r1e_*_pmc.txt of this workload, not collected by this run; "
-                                          "upper bound with FETCH doubled (gfx950 64-B tally): %d; algorithmic bytes are the %d-byte "
-                                          "image: the rest is the per-lane frame stack and register spills in scratch"
-                                          % (traffic[1], width * height * 3)) if traffic else "not measured for this configuration",
-                         "kernel": "trace_shade_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_flops_per_frame": float(counts[3]),
-                         "executed_f64_flops_per_frame": float(counts[4]),
-                         "node_visits": {"reference_defined": int(counts[7]), "f32_pre_tests": int(counts[5]),
-                                         "exact_f64_tests": int(counts[6])},
-                         "valu_busy_pmc": flops.MEASURED_VALU_BUSY.get(args.workload) if traffic else None,
-                         "executed": {"f64_tflops": executed, "frac_of_peak": executed / flops.FP64_VECTOR_PEAK_TFLOPS,
-                                      "frac_of_unfused_ceiling": executed / flops.FP64_UNFUSED_PEAK_TFLOPS},
-                         "note": "achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events x "
-                                 "the survey's flop constants / kernel time; the conservative pre-tests (f32 bounding spheres, "
-                                 "interval filter) answer most node visits without the f64 arithmetic, so this figure is not bounded "
-                                 "by the ALU peak (it is the flop-equivalent of Mrays/s).  `executed` is the f64 work really issued "
-                                 "against the same peak.  No dense contraction, so no MFMA; kernel_ms = slowest rank's average launch "
-                                 "time from HIP events on the launch stream (includes the tile-order probe launch when used)"},
-        }
+        roof = {"bound": "valu_fp64", "achieved": achieved, "peak": flops.FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / flops.FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": pmc["traffic_bytes"] if pmc else None,
+                "traffic_note": (("L2<->fabric bytes per frame (FETCH_SIZE + WRITE_SIZE, KiB units) from the rocprofv3 --pmc passes of "
+                                  "profiles/%s (git %s), not collected by this run; algorithmic bytes are the %d-byte image: the rest is the "
+                                  "per-lane frame stack and register spills in scratch") % (pmc["file"], pmc["git_rev"], width * height * 3))
+                if pmc else "no PMC record for this configuration",
+                "valu_issue_frac": pmc["valu_issue_frac"] if pmc else None,
+                "valu_busy_frac": pmc["valu_busy_frac"] if pmc else None,
+                "resident_waves": pmc["resident_waves"] if pmc else None,
+                "pmc_source": ({"file": "profiles/" + pmc["file"], "git_rev": pmc["git_rev"], "kernel_ms_in_pass": pmc["kernel_ms"]} if pmc else None),
+                "kernel": "trace_shade_kernel", "kernel_ms": kern_ms,
+                "algorithmic_flops_per_frame": float(counts[3]), "executed_f64_flops_per_frame": float(counts[4]),
+                "node_visits": {"reference_defined": int(counts[7]), "f32_pre_tests": int(counts[5]), "exact_f64_tests": int(counts[6])},
+                "executed": {"f64_tflops": executed, "frac_of_peak": executed / flops.FP64_VECTOR_PEAK_TFLOPS,
+                             "frac_of_unfused_ceiling": executed / flops.FP64_UNFUSED_PEAK_TFLOPS}}
+        rays_traced = rays_frame - int(counts[8]) if flops.SKIPS_BACKFACE_SHADOW_RAYS else rays_frame
+        return {"text": text, "width": width, "height": height, "desc": desc, "rays_frame": rays_frame, "elapsed": elapsed,
+                "value": rays_frame * steps / elapsed / 1e6, "ms_per_step": elapsed / steps * 1000.0,
+                "traced_mrays_per_s": rays_traced * steps / elapsed / 1e6, "rays_traced": rays_traced,
+                "rays": {"primary": int(counts[0]), "shadow": int(counts[1]), "secondary": int(counts[2])}, "roofline": roof}
+
+    m = measure(args.workload, args.width, args.height, args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        gather = ("row-interleaved 8-row bands x%d + one ncclAllGather per frame inside the product (rtx_render_gathered), "
+                  "overlapped with the next frame's render" % N) if comm is not None else \
+                 ("row-interleaved 8-row bands x%d, gloo REHEARSAL gather through host memory" % N if N > 1 else "1 GPU")
+        m["roofline"]["note"] = ("achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events x the survey's "
+                                 "flop constants / kernel time; the conservative pre-tests answer most node visits without the f64 arithmetic, so "
+                                 "this figure is not bounded by the ALU peak (it is the flop-equivalent of Mrays/s).  `executed` is the f64 work "
+                                 "really issued; valu_issue_frac = SQ_INSTS_VALU / (kernel cycles x 1024 SIMDs / 4) is the ALU-issue utilisation.  "
+                                 "No dense contraction, so no MFMA; kernel_ms = slowest rank's launch time from HIP events on the launch stream "
+                                 "(includes the tile-order probe launch when used)")
+        out = {"metric": "Mrays/sec (primary+shadow+secondary)", "value": m["value"], "unit": "Mrays/s", "n_gpus": N,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "%s: %s" % (args.workload, m["desc"]), "width": m["width"], "height": m["height"], "max_depth": 5,
+                          "rays_per_frame": m["rays_frame"], "rays": m["rays"], "parallelism": gather},
+               "traced_rays": {"rays_per_frame": m["rays_traced"], "mrays_per_s": m["traced_mrays_per_s"],
+                               "note": "rays the kernel really traces: shadow rays whose light is behind the surface (material.rs:67: the answer is "
+                                       "unused) are counted as the reference-defined rays they are but not traced" if flops.SKIPS_BACKFACE_SHADOW_RAYS
+                                       else "every reference-defined ray is traced"},
+               "roofline": m["roofline"]}
+    if N == 1 and not args.no_secondary and args.workload == "S4" and not args.width and not args.height:
+        s3 = measure("S3", 0, 0, args.steps, args.warmup)
+        if rank == 0:
+            out["secondary"] = {"config": {"workload": "S3: %s" % s3["desc"], "width": s3["width"], "height": s3["height"],
+                                           "rays_per_frame": s3["rays_frame"], "rays": s3["rays"]},
+                                "value": s3["value"], "unit": "Mrays/s", "ms_per_step": s3["ms_per_step"], "steps": args.steps,
+                                "roofline": s3["roofline"]}
+    if rank == 0:
         if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text, width, height)
+            out["cpu_baseline"] = cpu_baseline(m["text"], m["width"], m["height"])
         print(json.dumps(out), flush=True)
-    scene.close(); ctx.close()
+    if comm is not None:
+        comm.close()
+    ctx.close()
     if N > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def len_lights(text):
-    return text.count("- add: light")
 
 
 if __name__ == "__main__":

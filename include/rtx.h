@@ -188,6 +188,48 @@ int  rtx_render_device_noalloc(rtx_ctx*, const rtx_scene*, const rtx_camera*, in
 int  rtx_render_batch(rtx_ctx*, const rtx_scene*, const rtx_camera* cams, int n_cams, int max_depth,
                       uint32_t flags, uint8_t* const* rgb, int32_t* const* hit, rtx_stats* stats);
 
+/* ---- One frame on N GPUs (BASELINE.json north_star): the image is cut into row-interleaved 8-row tile
+ * bands, band b belongs to rank b % N, every rank renders its bands into a compact buffer, ONE RCCL all-gather over xGMI
+ * (ncclAllGather of rows_padded * W * 3 bytes per rank, ncclUint8) gives every rank all bands, and a copy kernel
+ * de-interleaves them into the row-major frame.  The reference has no counterpart (one thread, camera.rs:45-51); the call
+ * site is still main.rs:24.  librccl.so.1 is opened on the first rtx_comm_* call (not a load-time dependency).
+ *
+ * One process per GPU: rank 0 calls rtx_comm_unique_id and hands the RTX_COMM_ID_BYTES to the other ranks over the
+ * host's own channel; every rank calls rtx_comm_init_rank with its own context, then rtx_render_gathered per frame.
+ * One process, N GPUs: N contexts (rtx_init(i)), rtx_comm_init_all, one scene per context, rtx_render_multi. */
+typedef struct rtx_comm rtx_comm;
+#define RTX_COMM_ID_BYTES 128
+int  rtx_comm_unique_id(void* id /* RTX_COMM_ID_BYTES */);
+int  rtx_comm_init_rank(rtx_ctx*, const void* id, int rank, int world_size, rtx_comm** out);
+int  rtx_comm_init_all(rtx_ctx* const* ctxs, int n, rtx_comm** out /* n handles */);
+void rtx_comm_destroy(rtx_comm*);
+int  rtx_comm_rank(const rtx_comm*);
+int  rtx_comm_size(const rtx_comm*);
+
+/* Camera::render (camera.rs:39-54) on all ranks of `comm`: queues this rank's bands on `stream` (NULL = the context's),
+ * then the all-gather and the de-interleave on the communicator's own stream, so the next frame's render overlaps this
+ * frame's gather (two internal buffer sets).  d_frame: hsize*vsize*3 device bytes, row-major, complete on EVERY rank;
+ * d_hit_frame: NULL or hsize*vsize int32.  Returns once everything is queued; the frame is ready after rtx_comm_wait.
+ * stats != NULL waits for this rank's render and returns ITS share's counts.  scene must belong to comm's context. */
+int  rtx_render_gathered(rtx_comm*, const rtx_scene*, const rtx_camera*, int max_depth, uint32_t flags,
+                         void* d_frame, void* d_hit_frame, void* stream, rtx_stats* stats);
+/* Makes `stream` wait (on the device) for the last rtx_render_gathered's frame; stream == NULL: the HOST waits, and the
+ * sticky error of the context (rtx_ctx_poll) is returned. */
+int  rtx_comm_wait(rtx_comm*, void* stream);
+
+/* The same frame from ONE host thread that owns all N GPUs: comms[i] / scenes[i] belong to rank i (rtx_comm_init_all;
+ * the same scene description uploaded to every context).  Renders, gathers (one grouped all-gather), assembles on rank
+ * 0's GPU and copies to host buffers (rgb: hsize*vsize*3, hit: NULL or hsize*vsize int32).  stats: NULL or the whole
+ * frame's counts (sum over ranks).  With n == 1 the same calls run with a one-rank communicator. */
+int  rtx_render_multi(rtx_comm* const* comms, const rtx_scene* const* scenes, int n, const rtx_camera*, int max_depth,
+                      uint32_t flags, uint8_t* rgb, int32_t* hit, rtx_stats* stats);
+
+/* Host-side de-interleave for callers that gather compact band buffers (RTX_F_BANDS_COMPACT) with a transport of their
+ * own: gathered = n_ranks buffers of rtx_band_rows_padded() rows back to back, frame = height rows.  Row y of the image is
+ * row (y/8/N)*8 + y%8 of rank (y/8) % N. */
+int  rtx_band_rows_padded(int vsize, int n_ranks);
+int  rtx_band_deinterleave(const uint8_t* gathered, int n_ranks, int width, int height, int bytes_per_pixel, uint8_t* frame);
+
 /* rows (padded to whole bands) a rank holds under `bands`, i.e. the compact buffer height */
 int  rtx_band_rows(int vsize, rtx_bands bands);
 

@@ -96,6 +96,9 @@ const char* rtxh_last_error(void);
 int  rtxh_write_png(const char* path, const uint8_t* rgb, int width, int height);
 /* main.rs:20-28: load scene file, render cameras[0] on `device`, write <stem>.png into out_dir */
 int  rtxh_render_file(const char* yaml_path, const char* out_dir, int device);
+/* The same on n_gpus GPUs of this node (0 = all visible; one process, one context per GPU): cameras[0] is cut into
+ * row-interleaved tile bands, one band set per GPU, gathered with RCCL (rtx_render_multi in rtx.h). */
+int  rtxh_render_file_gpus(const char* yaml_path, const char* out_dir, int n_gpus);
 /* N4: the same for EVERY camera of the file through rtx_render_batch (scene uploaded once): cameras[0] ->
  * <stem>.png as above, cameras[i>0] -> <stem>.cam<i>.png.  n_rendered_out (may be NULL) = images written. */
 int  rtxh_render_file_all(const char* yaml_path, const char* out_dir, int device, int* n_rendered_out);

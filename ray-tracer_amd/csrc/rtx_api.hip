@@ -537,7 +537,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         heads[i].run = run;
     }
     for (size_t i = cc.ops.size(); i < heads.size(); i++) { heads[i].info = OPK_GROUP_END; heads[i].cull[3] = INFINITY; }   // padding, never executed
-    if (ctx->opt.debug)
+    if (ctx->opt.debug == 1)
         for (size_t i = 0; i < heads.size(); i++)
             fprintf(stderr, "head %zu: info=%08x skip=%d shape=%d cull=%g %g %g %g\n", i, heads[i].info, heads[i].skip,
                     heads[i].shape, heads[i].cull[0], heads[i].cull[1], heads[i].cull[2], heads[i].cull[3]);
@@ -696,6 +696,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 // (2^(d+1) - 1) * (1 + n_lights) traces, the bound leaves 4x room on top of 16 pixels per wave
                 const long long g = 4ll * 16 * (2ll << max_depth) * (1 + scene->dev.n_lights);
                 rp.split_guard = (int32_t)(g > 0x3fffffff ? 0x3fffffff : g);
+                if (ctx->opt.debug == 2) rp.split_guard = 1;        // test hook: every split wave gives up (sticky-error test)
             }
         }
     }

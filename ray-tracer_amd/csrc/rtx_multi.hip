@@ -1,0 +1,370 @@
+// rtx_multi.hip — one frame on N GPUs: row-interleaved 8-row tile bands, one band set per GPU, gathered with an
+// RCCL all-gather over xGMI and de-interleaved into the row-major frame (BASELINE.json north_star).
+//
+// The reference has no counterpart (single thread, camera.rs:45-51); the seam is still main.rs:24: ONE call renders
+// cameras[0], on however many GPUs the host was given.  Two ways to own the GPUs:
+//   * one process per GPU  — rtx_comm_unique_id on rank 0, the host hands the 128 bytes to the other ranks over its
+//     own channel, every rank calls rtx_comm_init_rank and then rtx_render_gathered per frame;
+//   * one process, N GPUs  — rtx_comm_init_all over N contexts, rtx_render_multi per frame (what `rtx --gpus N` does).
+// RCCL (librccl.so.1, 570 MB) is opened on the first rtx_comm_* call, not at load time: single-GPU users never map it,
+// and in a process that already carries an RCCL (PyTorch-ROCm) the same copy is used.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_internal.h"
+
+namespace {
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    if (r.so || !r.err.empty()) return &r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.so) break;
+    }
+    if (!r.so) { r.err = std::string("cannot open librccl.so.1: ") + dlerror(); return &r; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!r.err.empty()) { dlclose(r.so); r.so = nullptr; }
+    return &r;
+}
+
+// gathered: [rank][rows_pad][row_bytes] (what the all-gather leaves); frame: [height][row_bytes].
+// Image row y lies in band y / 8, which rank (y / 8) % n rendered as its ((y / 8) / n)-th band.
+template <typename T>
+__global__ void deinterleave_kernel(const T* __restrict__ gathered, T* __restrict__ frame, int height, long long row_elems,
+                                    int n, long long rows_pad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)height * row_elems) return;
+    const int y = (int)(i / row_elems);
+    const long long x = i - (long long)y * row_elems;
+    const int band = y / RTX_TILE;
+    const long long src_row = (long long)(band % n) * rows_pad + (long long)(band / n) * RTX_TILE + (y % RTX_TILE);
+    frame[i] = gathered[src_row * row_elems + x];
+}
+
+int rows_padded(int vsize, int n) { return ((vsize + RTX_TILE - 1) / RTX_TILE + n - 1) / n * RTX_TILE; }
+
+}  // namespace
+
+struct rtx_comm {
+    rtx_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;
+    hipStream_t gstream = nullptr;               // the gather runs here, beside the next frame's render
+    // two buffer sets: frame k renders into set k & 1 while frame k - 1's set is still being gathered
+    uint8_t* d_band[2] = {nullptr, nullptr}; uint8_t* d_all[2] = {nullptr, nullptr}; size_t band_cap = 0;
+    int32_t* d_band_hit[2] = {nullptr, nullptr}; int32_t* d_all_hit[2] = {nullptr, nullptr}; size_t hit_cap = 0;
+    hipEvent_t ev_render[2] = {nullptr, nullptr}, ev_gather[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    unsigned seq = 0;
+    // what the last rtx_comm_render_bands queued, for the gather step
+    int cur = 0; int W = 0, H = 0; bool want_hit = false;
+};
+
+namespace {
+
+int nccl_fail(rtx_ctx* ctx, const char* what, ncclResult_t r) {
+    return rtx_fail(ctx, RTX_E_DEVICE, std::string(what) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error"));
+}
+#define NCCLCHK(ctx, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return nccl_fail(ctx, #call, r_); } while (0)
+
+int comm_finish_init(rtx_comm* c) {
+    rtx_ctx* ctx = c->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_render[b], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_gather[b], hipEventDisableTiming));
+    }
+    return RTX_OK;
+}
+
+int comm_reserve(rtx_comm* c, int W, int H, bool want_hit) {
+    rtx_ctx* ctx = c->ctx;
+    const size_t band_px = (size_t)rows_padded(H, c->world) * W;
+    if (band_px * 3 > c->band_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(c->gstream));
+        for (int b = 0; b < 2; b++) {
+            if (c->d_band[b]) (void)hipFree(c->d_band[b]);
+            if (c->d_all[b]) (void)hipFree(c->d_all[b]);
+            c->d_band[b] = c->d_all[b] = nullptr;
+        }
+        c->band_cap = 0;
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(ctx, hipMalloc((void**)&c->d_band[b], band_px * 3));
+            HIPCHK(ctx, hipMalloc((void**)&c->d_all[b], band_px * 3 * c->world));
+            HIPCHK(ctx, hipMemset(c->d_band[b], 0, band_px * 3));              // (the padding rows of the last band are sent too)
+        }
+        c->band_cap = band_px * 3;
+    }
+    if (want_hit && band_px * 4 > c->hit_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(c->gstream));
+        for (int b = 0; b < 2; b++) {
+            if (c->d_band_hit[b]) (void)hipFree(c->d_band_hit[b]);
+            if (c->d_all_hit[b]) (void)hipFree(c->d_all_hit[b]);
+            c->d_band_hit[b] = c->d_all_hit[b] = nullptr;
+        }
+        c->hit_cap = 0;
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(ctx, hipMalloc((void**)&c->d_band_hit[b], band_px * 4));
+            HIPCHK(ctx, hipMalloc((void**)&c->d_all_hit[b], band_px * 4 * c->world));
+            HIPCHK(ctx, hipMemset(c->d_band_hit[b], 0xff, band_px * 4));
+        }
+        c->hit_cap = band_px * 4;
+    }
+    return RTX_OK;
+}
+
+// step 1: this rank's bands {rank, world}, compact, into the current buffer set, on `st`
+int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam, int max_depth, uint32_t flags,
+                      bool want_hit, hipStream_t st, rtx_stats* stats) {
+    rtx_ctx* ctx = c->ctx;
+    if (!scene || !cam) return RTX_E_INVALID;
+    if (cam->hsize <= 0 || cam->vsize <= 0) return rtx_fail(ctx, RTX_E_INVALID, "empty camera");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = comm_reserve(c, cam->hsize, cam->vsize, want_hit);
+    if (rc != RTX_OK) return rc;
+    const int b = (int)(c->seq & 1u);
+    if (c->used[b]) HIPCHK(ctx, hipStreamWaitEvent(st, c->ev_gather[b], 0));      // the set's previous gather has read it
+    rc = rtx_render_device(ctx, scene, cam, max_depth, rtx_bands{c->rank, c->world}, flags | RTX_F_BANDS_COMPACT,
+                           c->d_band[b], want_hit ? c->d_band_hit[b] : nullptr, st, stats);
+    if (rc != RTX_OK) return rc;
+    HIPCHK(ctx, hipEventRecord(c->ev_render[b], st));
+    c->cur = b; c->W = cam->hsize; c->H = cam->vsize; c->want_hit = want_hit;
+    return RTX_OK;
+}
+
+// step 2 (inside a group when one thread drives several ranks): the all-gather of the current set, on gstream
+int comm_all_gather(rtx_comm* c) {
+    rtx_ctx* ctx = c->ctx;
+    const int b = c->cur;
+    const size_t band_px = (size_t)rows_padded(c->H, c->world) * c->W;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamWaitEvent(c->gstream, c->ev_render[b], 0));
+    NCCLCHK(ctx, rccl()->AllGather(c->d_band[b], c->d_all[b], band_px * 3, ncclUint8, c->nccl, c->gstream));
+    if (c->want_hit) NCCLCHK(ctx, rccl()->AllGather(c->d_band_hit[b], c->d_all_hit[b], band_px, ncclInt32, c->nccl, c->gstream));
+    return RTX_OK;
+}
+
+// step 3: de-interleave into the caller's row-major frame (gstream), mark the set reusable
+int comm_deinterleave(rtx_comm* c, void* d_frame, void* d_hit_frame) {
+    rtx_ctx* ctx = c->ctx;
+    const int b = c->cur;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long long rows_pad = rows_padded(c->H, c->world);
+    if (d_frame) {
+        const long long row_bytes = (long long)c->W * 3;
+        if (row_bytes % 16 == 0 && ((uintptr_t)d_frame % 16) == 0) {
+            const long long n = (long long)c->H * (row_bytes / 16);
+            hipLaunchKernelGGL(deinterleave_kernel<uint4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->gstream,
+                               (const uint4*)c->d_all[b], (uint4*)d_frame, c->H, row_bytes / 16, c->world, rows_pad);
+        } else {
+            const long long n = (long long)c->H * row_bytes;
+            hipLaunchKernelGGL(deinterleave_kernel<uint8_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->gstream,
+                               (const uint8_t*)c->d_all[b], (uint8_t*)d_frame, c->H, row_bytes, c->world, rows_pad);
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (d_hit_frame && c->want_hit) {
+        const long long n = (long long)c->H * c->W;
+        hipLaunchKernelGGL(deinterleave_kernel<int32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->gstream,
+                           (const int32_t*)c->d_all_hit[b], (int32_t*)d_hit_frame, c->H, (long long)c->W, c->world, rows_pad);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(c->ev_gather[b], c->gstream));
+    c->used[b] = true;
+    c->seq++;
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_comm_unique_id(void* id) {
+    if (!id) return RTX_E_INVALID;
+    Rccl* r = rccl();
+    if (!r->so) return RTX_E_DEVICE;
+    ncclUniqueId u;
+    if (r->GetUniqueId(&u) != ncclSuccess) return RTX_E_DEVICE;
+    static_assert(sizeof(u) == RTX_COMM_ID_BYTES, "RTX_COMM_ID_BYTES must be RCCL's unique id size");
+    std::memcpy(id, &u, sizeof u);
+    return RTX_OK;
+}
+
+int rtx_comm_init_rank(rtx_ctx* ctx, const void* id, int rank, int world_size, rtx_comm** out) {
+    if (!ctx || !id || !out || world_size < 1 || rank < 0 || rank >= world_size) return RTX_E_INVALID;
+    *out = nullptr;
+    Rccl* r = rccl();
+    if (!r->so) return rtx_fail(ctx, RTX_E_DEVICE, r->err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rtx_comm* c = new rtx_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world_size;
+    ncclUniqueId u; std::memcpy(&u, id, sizeof u);
+    ncclResult_t nr = r->CommInitRank(&c->nccl, world_size, u, rank);
+    if (nr != ncclSuccess) { delete c; return nccl_fail(ctx, "ncclCommInitRank", nr); }
+    int rc = comm_finish_init(c);
+    if (rc != RTX_OK) { rtx_comm_destroy(c); return rc; }
+    *out = c;
+    return RTX_OK;
+}
+
+int rtx_comm_init_all(rtx_ctx* const* ctxs, int n, rtx_comm** out) {
+    if (!ctxs || !out || n < 1) return RTX_E_INVALID;
+    for (int i = 0; i < n; i++) { out[i] = nullptr; if (!ctxs[i]) return RTX_E_INVALID; }
+    Rccl* r = rccl();
+    if (!r->so) return rtx_fail(ctxs[0], RTX_E_DEVICE, r->err);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) {
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return rtx_fail(ctxs[0], RTX_E_INVALID, "rtx_comm_init_all: two contexts on one device");
+    }
+    std::vector<ncclComm_t> nc(n, nullptr);
+    ncclResult_t nr = r->CommInitAll(nc.data(), n, devs.data());
+    if (nr != ncclSuccess) return nccl_fail(ctxs[0], "ncclCommInitAll", nr);
+    int rc = RTX_OK;
+    for (int i = 0; i < n; i++) {
+        rtx_comm* c = new rtx_comm();
+        c->ctx = ctxs[i]; c->rank = i; c->world = n; c->nccl = nc[i];
+        out[i] = c;
+        if (rc == RTX_OK) rc = comm_finish_init(c);
+    }
+    if (rc != RTX_OK) for (int i = 0; i < n; i++) { rtx_comm_destroy(out[i]); out[i] = nullptr; }
+    return rc;
+}
+
+void rtx_comm_destroy(rtx_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+    if (c->nccl && rccl()->so) (void)rccl()->CommDestroy(c->nccl);
+    for (int b = 0; b < 2; b++) {
+        for (void* p : {(void*)c->d_band[b], (void*)c->d_all[b], (void*)c->d_band_hit[b], (void*)c->d_all_hit[b]}) if (p) (void)hipFree(p);
+        if (c->ev_render[b]) (void)hipEventDestroy(c->ev_render[b]);
+        if (c->ev_gather[b]) (void)hipEventDestroy(c->ev_gather[b]);
+    }
+    if (c->gstream) (void)hipStreamDestroy(c->gstream);
+    delete c;
+}
+
+int rtx_comm_rank(const rtx_comm* c) { return c ? c->rank : -1; }
+int rtx_comm_size(const rtx_comm* c) { return c ? c->world : 0; }
+
+int rtx_render_gathered(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam, int max_depth, uint32_t flags,
+                        void* d_frame, void* d_hit_frame, void* stream, rtx_stats* stats) {
+    if (!c || !d_frame) return RTX_E_INVALID;
+    hipStream_t st = stream ? (hipStream_t)stream : c->ctx->stream;
+    int rc = comm_render_bands(c, scene, cam, max_depth, flags, d_hit_frame != nullptr, st, stats);
+    if (rc == RTX_OK) rc = comm_all_gather(c);
+    if (rc == RTX_OK) rc = comm_deinterleave(c, d_frame, d_hit_frame);
+    return rc;
+}
+
+int rtx_comm_wait(rtx_comm* c, void* stream) {
+    if (!c) return RTX_E_INVALID;
+    rtx_ctx* ctx = c->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!stream) { HIPCHK(ctx, hipStreamSynchronize(c->gstream)); return rtx_ctx_poll(ctx, 0); }
+    const int last = (int)((c->seq + 1u) & 1u);                    // the set of the most recent frame
+    if (c->used[last]) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, c->ev_gather[last], 0));
+    return RTX_OK;
+}
+
+int rtx_render_multi(rtx_comm* const* comms, const rtx_scene* const* scenes, int n, const rtx_camera* cam, int max_depth,
+                     uint32_t flags, uint8_t* rgb, int32_t* hit, rtx_stats* stats) {
+    if (!comms || !scenes || n < 1 || !cam || !rgb) return RTX_E_INVALID;
+    for (int i = 0; i < n; i++) if (!comms[i] || !scenes[i] || comms[i]->world != n || comms[i]->rank != i) return RTX_E_INVALID;
+    rtx_ctx* ctx0 = comms[0]->ctx;
+    if (cam->hsize <= 0 || cam->vsize <= 0) return rtx_fail(ctx0, RTX_E_INVALID, "empty camera");
+    const size_t npx = (size_t)cam->hsize * cam->vsize;
+    // the whole frame lands on rank 0's GPU (every rank receives all bands; only rank 0 de-interleaves here)
+    HIPCHK(ctx0, hipSetDevice(ctx0->device));
+    if (npx * 3 > ctx0->rgb_cap) {
+        if (ctx0->d_rgb) (void)hipFree(ctx0->d_rgb);
+        ctx0->d_rgb = nullptr; ctx0->rgb_cap = 0;
+        HIPCHK(ctx0, hipMalloc((void**)&ctx0->d_rgb, npx * 3));
+        ctx0->rgb_cap = npx * 3;
+    }
+    if (hit && npx * 4 > ctx0->hit_cap) {
+        if (ctx0->d_hit) (void)hipFree(ctx0->d_hit);
+        ctx0->d_hit = nullptr; ctx0->hit_cap = 0;
+        HIPCHK(ctx0, hipMalloc((void**)&ctx0->d_hit, npx * 4));
+        ctx0->hit_cap = npx * 4;
+    }
+    // every GPU renders its bands (queued, nothing waits) ...
+    std::vector<rtx_stats> per(n);
+    int rc = RTX_OK;
+    for (int i = 0; i < n && rc == RTX_OK; i++)
+        rc = comm_render_bands(comms[i], scenes[i], cam, max_depth, flags, hit != nullptr, comms[i]->ctx->stream, stats ? &per[i] : nullptr);
+    if (rc != RTX_OK) { if (comms[0]->ctx->err.empty()) for (int i = 1; i < n; i++) if (!comms[i]->ctx->err.empty()) ctx0->err = comms[i]->ctx->err; return rc; }
+    // ... one all-gather over all ranks (one thread drives them: a group) ...
+    NCCLCHK(ctx0, rccl()->GroupStart());
+    for (int i = 0; i < n && rc == RTX_OK; i++) rc = comm_all_gather(comms[i]);
+    NCCLCHK(ctx0, rccl()->GroupEnd());
+    // ... rank 0 assembles the frame and hands it to the host
+    for (int i = 0; i < n && rc == RTX_OK; i++) rc = comm_deinterleave(comms[i], i == 0 ? ctx0->d_rgb : nullptr, i == 0 && hit ? ctx0->d_hit : nullptr);
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(comms[i]->ctx->device);
+        if (hipStreamSynchronize(comms[i]->gstream) != hipSuccess && rc == RTX_OK) rc = rtx_fail(ctx0, RTX_E_DEVICE, "hipStreamSynchronize failed");
+        if (rc == RTX_OK) { rc = rtx_ctx_poll(comms[i]->ctx, 0); if (rc != RTX_OK && i > 0) ctx0->err = comms[i]->ctx->err; }
+    }
+    if (rc != RTX_OK) return rc;
+    HIPCHK(ctx0, hipSetDevice(ctx0->device));
+    HIPCHK(ctx0, hipMemcpy(rgb, ctx0->d_rgb, npx * 3, hipMemcpyDeviceToHost));
+    if (hit) HIPCHK(ctx0, hipMemcpy(hit, ctx0->d_hit, npx * 4, hipMemcpyDeviceToHost));
+    if (stats) {
+        // the frame's counts are the sums of the ranks' shares (with stats every rank's launch was waited for in turn,
+        // so kernel_ms is the slowest rank's, not a concurrent measurement)
+        std::memset(stats, 0, sizeof *stats);
+        for (int i = 0; i < n; i++) {
+            stats->rays_primary += per[i].rays_primary; stats->rays_shadow += per[i].rays_shadow; stats->rays_secondary += per[i].rays_secondary;
+            for (int k = 0; k < RTX_EV_COUNT; k++) stats->ev[k] += per[i].ev[k];
+            stats->overflow_pixels += per[i].overflow_pixels;
+            if (per[i].kernel_ms > stats->kernel_ms) stats->kernel_ms = per[i].kernel_ms;
+        }
+    }
+    return RTX_OK;
+}
+
+int rtx_band_rows_padded(int vsize, int n_ranks) { return (vsize > 0 && n_ranks > 0) ? rows_padded(vsize, n_ranks) : 0; }
+
+int rtx_band_deinterleave(const uint8_t* gathered, int n_ranks, int width, int height, int bytes_per_pixel, uint8_t* frame) {
+    if (!gathered || !frame || n_ranks < 1 || width <= 0 || height <= 0 || bytes_per_pixel <= 0) return RTX_E_INVALID;
+    const size_t row = (size_t)width * bytes_per_pixel;
+    const size_t rows_pad = (size_t)rows_padded(height, n_ranks);
+    for (int y = 0; y < height; y++) {
+        const int band = y / RTX_TILE;
+        const size_t src = (size_t)(band % n_ranks) * rows_pad + (size_t)(band / n_ranks) * RTX_TILE + (y % RTX_TILE);
+        std::memcpy(frame + (size_t)y * row, gathered + src * row, row);
+    }
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -59,6 +59,58 @@ int rtxh_render_file(const char* yaml_path, const char* out_dir, int device) {
     return rtxh_write_png(out.c_str(), rgb.data(), cam.hsize, cam.vsize);
 }
 
+// main.rs:20-28 with cameras[0] rendered on n_gpus GPUs of this node (0 = all visible): row-interleaved tile bands,
+// one band set per GPU, gathered with RCCL (rtx_render_multi)
+int rtxh_render_file_gpus(const char* yaml_path, const char* out_dir, int n_gpus) {
+    if (!yaml_path || n_gpus < 0) return RTX_E_INVALID;
+    std::ifstream in(yaml_path, std::ios::binary);
+    if (!in) { g_err = std::string("cannot read ") + yaml_path; return RTX_E_INVALID; }
+    std::stringstream ss; ss << in.rdbuf();
+    rtxh_world* w = nullptr; rtxh_camera cam; int ncam = 0;
+    int rc = rtxh_load_yaml(ss.str().c_str(), &w, &cam, 1, &ncam);
+    if (rc != RTX_OK) return rc;
+    if (ncam < 1) { g_err = "scene has no camera"; rtxh_world_free(w); return RTX_E_INVALID; }
+    std::vector<rtx_ctx*> ctxs;
+    std::vector<rtx_comm*> comms;
+    std::vector<rtx_scene*> scenes;
+    for (int i = 0; n_gpus == 0 || i < n_gpus; i++) {
+        rtx_ctx* c = nullptr;
+        rc = rtx_init(i, &c);
+        if (rc != RTX_OK) { if (n_gpus == 0 && i > 0) rc = RTX_OK; break; }      // 0 = as many as there are
+        ctxs.push_back(c);
+    }
+    const int n = (int)ctxs.size();
+    if (rc != RTX_OK || n == 0) { g_err = "rtx_init failed: fewer usable HIP devices than requested"; if (rc == RTX_OK) rc = RTX_E_DEVICE; }
+    if (rc == RTX_OK) {
+        comms.assign(n, nullptr);
+        rc = rtx_comm_init_all(ctxs.data(), n, comms.data());
+        if (rc != RTX_OK) g_err = rtx_last_error(ctxs[0]);
+    }
+    for (int i = 0; i < n && rc == RTX_OK; i++) {
+        rtx_scene* s = nullptr;
+        rc = rtxh_scene_create(ctxs[i], w, &s);
+        if (rc != RTX_OK) g_err = rtx_last_error(ctxs[i]); else scenes.push_back(s);
+    }
+    std::vector<uint8_t> rgb((size_t)cam.hsize * cam.vsize * 3);
+    if (rc == RTX_OK) {
+        rtx_camera flat; rtxh_camera_flatten(&cam, &flat);
+        rc = rtx_render_multi(comms.data(), scenes.data(), n, &flat, 5 /* camera.rs:42 */, 0, rgb.data(), nullptr, nullptr);
+        if (rc != RTX_OK) g_err = rtx_last_error(ctxs[0]);
+    }
+    for (rtx_scene* s : scenes) rtx_scene_destroy(s);
+    for (rtx_comm* c : comms) rtx_comm_destroy(c);
+    for (rtx_ctx* c : ctxs) rtx_shutdown(c);
+    rtxh_world_free(w);
+    if (rc != RTX_OK) return rc;
+    std::string p(yaml_path);
+    size_t sl = p.find_last_of('/');
+    std::string name = sl == std::string::npos ? p : p.substr(sl + 1);
+    size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) name = name.substr(0, dot);
+    std::string out = (out_dir && *out_dir) ? std::string(out_dir) + "/" + name + ".png" : name + ".png";
+    return rtxh_write_png(out.c_str(), rgb.data(), cam.hsize, cam.vsize);
+}
+
 int rtxh_render_file_all(const char* yaml_path, const char* out_dir, int device, int* n_rendered_out) {
     if (n_rendered_out) *n_rendered_out = 0;
     if (!yaml_path) return RTX_E_INVALID;

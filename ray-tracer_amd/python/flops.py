@@ -50,28 +50,47 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6     # 256 CU x 64 lanes x 2 (FMA) x 2.4 GHz (MI35
 FP64_UNFUSED_PEAK_TFLOPS = 39.3    # one flop per lane-issue: the ceiling for parity code (no a*b+c fusion)
 
 
-# L2 <-> fabric traffic of one trace_shade_kernel launch at the bench's default size on ONE GPU, from separate
-# rocprofv3 --pmc passes (tools/pmc_passes.sh; summaries in profiles/r1e_*_pmc.txt, r1f for S4).  Units: the counters
-# report KiB (checked against a 24 883 200-byte fill in the same trace: WRITE_SIZE 24300.0).  FETCH_SIZE on
-# gfx950 tallies 128-B requests at 64 B for wide coalesced reads and is uncalibrated for other widths
-# (MI355X_MICROARCH.md, HBM); this kernel's fabric reads are scratch re-loads (4-16 B per lane), so FETCH is
-# given as counted and the doubled figure as the upper bound.  bench.py cannot collect counters itself; it
-# quotes these numbers only for the exact workload they were measured on.
-MEASURED_TRAFFIC_KIB = {          # workload: (FETCH_SIZE, WRITE_SIZE) per launch
-    "S3": (63663, 688858),
-    "S4": (2670007, 7179379),      # frame launch + tile-order probe launch (profiles/r1f_S4_pmc.txt)
-    "S5": (427135, 8269739),
-}
+# ---- PMC record of the profiled revision (tools/profile_round.sh -> tools/pmc_counters.py -> profiles/<tag>_counters.json).
+# bench.py cannot collect counters itself; it quotes the newest record, with the git revision and the kernel time the
+# passes were taken at, and only for the exact workload and size they were measured on.  Units: FETCH_SIZE / WRITE_SIZE
+# report KiB (checked against a 24 883 200-byte fill in the same trace: WRITE_SIZE 24300.0).  FETCH_SIZE on gfx950
+# tallies 128-B requests at 64 B for wide coalesced reads and is uncalibrated for other widths (MI355X_MICROARCH.md, HBM);
+# this kernel's fabric reads are scratch re-loads (4-16 B per lane), so FETCH is given as counted.
+import glob
+import json
+import os
+
+_PROFILES = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles")
+N_SIMD = 1024          # 256 CUs x 4
+N_XCD = 8
 
 
-def measured_traffic_bytes(workload):
-    """-> (bytes as counted, upper bound with FETCH doubled) or None"""
-    t = MEASURED_TRAFFIC_KIB.get(workload)
-    if t is None:
+def newest_counter_file():
+    files = sorted(glob.glob(os.path.join(_PROFILES, "*_counters.json")))
+    return files[-1] if files else None
+
+
+def pmc_counters(workload, path=None):
+    """-> derived figures of the newest PMC record for `workload`, or None.
+    valu_issue_frac = SQ_INSTS_VALU / (kernel cycles x 1024 SIMDs / 4 cycles per wave64 instruction)
+    valu_busy_frac  = SQ_ACTIVE_INST_VALU x 4 / (kernel cycles x 1024)
+    resident_waves  = SQ_WAVE_CYCLES x 4 / kernel cycles          (kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs)"""
+    path = path or newest_counter_file()
+    if not path:
         return None
-    return (t[0] + t[1]) * 1024, (2 * t[0] + t[1]) * 1024
+    rec = json.load(open(path))
+    w = rec.get("workloads", {}).get(workload)
+    if not w:
+        return None
+    c = w["frame"]                                   # per frame: frame launch (+ probe / split launches when used)
+    cyc = c["GRBM_GUI_ACTIVE"] / N_XCD
+    return {"file": os.path.basename(path), "git_rev": rec.get("git_rev"), "kernel_ms": w.get("kernel_ms"),
+            "traffic_bytes": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+            "fetch_bytes": int(c["FETCH_SIZE"] * 1024), "write_bytes": int(c["WRITE_SIZE"] * 1024),
+            "valu_issue_frac": c["SQ_INSTS_VALU"] / (cyc * N_SIMD / 4.0),
+            "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * N_SIMD),
+            "resident_waves": c["SQ_WAVE_CYCLES"] * 4.0 / cyc}
 
 
-# VALU pipe utilisation of the frame launch from the same committed PMC passes:
-# SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
-MEASURED_VALU_BUSY = {"S4": 0.71}
+# the kernel skips shadow rays whose light is behind the surface (material.rs:67: the answer is unused); they stay counted
+SKIPS_BACKFACE_SHADOW_RAYS = False

@@ -68,7 +68,9 @@ class SceneDesc(C.Structure):
 # every symbol include/rtx.h and include/rtx_host.h declare
 RTX_SYMBOLS = ["rtx_init", "rtx_shutdown", "rtx_scene_create", "rtx_scene_destroy", "rtx_render",
                "rtx_render_device", "rtx_render_device_noalloc", "rtx_ctx_poll", "rtx_set_option",
-               "rtx_render_batch", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
+               "rtx_comm_unique_id", "rtx_comm_init_rank", "rtx_comm_init_all", "rtx_comm_destroy", "rtx_comm_rank",
+               "rtx_comm_size", "rtx_render_gathered", "rtx_comm_wait", "rtx_render_multi", "rtx_band_rows_padded",
+               "rtx_band_deinterleave", "rtx_render_batch", "rtx_band_rows", "rtx_debug_math", "rtx_strerror", "rtx_last_error"]
 RTXH_SYMBOLS = ["rtxh_identity", "rtxh_translation", "rtxh_scaling", "rtxh_rotation_x", "rtxh_rotation_y",
                 "rtxh_rotation_z", "rtxh_view_transform", "rtxh_mat_mul", "rtxh_inverse",
                 "rtxh_default_material", "rtxh_world_new", "rtxh_world_free", "rtxh_add_shape",
@@ -76,7 +78,7 @@ RTXH_SYMBOLS = ["rtxh_identity", "rtxh_translation", "rtxh_scaling", "rtxh_rotat
                 "rtxh_add_light", "rtxh_build", "rtxh_set_material_of", "rtxh_get_material_of",
                 "rtxh_set_light", "rtxh_get_bounds", "rtxh_camera_new", "rtxh_world_serialize", "rtxh_scene_create",
                 "rtxh_camera_flatten", "rtxh_render", "rtxh_load_yaml", "rtxh_last_error",
-                "rtxh_write_png", "rtxh_render_file", "rtxh_render_file_all"]
+                "rtxh_write_png", "rtxh_render_file", "rtxh_render_file_all", "rtxh_render_file_gpus"]
 
 
 def _load():
@@ -96,6 +98,14 @@ def _load():
         "rtx_ctx_poll": (i, [vp, i]), "rtx_set_option": (i, [vp, C.c_char_p, i]),
         "rtx_render_batch": (i, [vp, vp, C.POINTER(RtxCamera), i, i, u32, C.POINTER(pu8), C.POINTER(pi32), C.POINTER(Stats)]),
         "rtx_band_rows": (i, [i, Bands]),
+        "rtx_comm_unique_id": (i, [vp]), "rtx_comm_init_rank": (i, [vp, vp, i, i, C.POINTER(vp)]),
+        "rtx_comm_init_all": (i, [C.POINTER(vp), i, C.POINTER(vp)]), "rtx_comm_destroy": (None, [vp]),
+        "rtx_comm_rank": (i, [vp]), "rtx_comm_size": (i, [vp]),
+        "rtx_render_gathered": (i, [vp, vp, C.POINTER(RtxCamera), i, u32, vp, vp, vp, C.POINTER(Stats)]),
+        "rtx_comm_wait": (i, [vp, vp]),
+        "rtx_render_multi": (i, [C.POINTER(vp), C.POINTER(vp), i, C.POINTER(RtxCamera), i, u32, pu8, pi32, C.POINTER(Stats)]),
+        "rtx_band_rows_padded": (i, [i, i]), "rtx_band_deinterleave": (i, [pu8, i, i, i, i, pu8]),
+        "rtxh_render_file_gpus": (i, [C.c_char_p, C.c_char_p, i]),
         "rtx_debug_math": (i, [vp, i, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rtx_strerror": (C.c_char_p, [i]), "rtx_last_error": (C.c_char_p, [vp]),
         "rtxh_scene_create": (i, [vp, vp, C.POINTER(vp)]),
@@ -251,6 +261,80 @@ class Scene:
                                    C.c_void_p(stream) if stream else None, C.byref(st) if stats else None)
         self.ctx._check(rc)
         return st
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rtx_comm_unique_id: 128 bytes rank 0 creates and the host hands to the other ranks."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = LIB.rtx_comm_unique_id(buf)
+    if rc != OK:
+        raise RtxError(rc, "rtx_comm_unique_id: RCCL is not available")
+    return buf.raw
+
+
+class Comm:
+    """rtx_comm of one rank (one process per GPU): bands {rank, world} + RCCL all-gather + de-interleave."""
+
+    def __init__(self, ctx, unique_id, rank, world, handle=None):
+        self.ctx = ctx
+        if handle is not None:
+            self.h = handle
+            return
+        h = C.c_void_p()
+        ctx._check(LIB.rtx_comm_init_rank(ctx.h, C.c_char_p(unique_id), rank, world, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def init_all(ctxs):
+        """rtx_comm_init_all: one process, one context per GPU -> [Comm]"""
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c.h for c in ctxs]); out = (C.c_void_p * n)()
+        ctxs[0]._check(LIB.rtx_comm_init_all(hs, n, out))
+        return [Comm(ctxs[k], None, k, n, handle=C.c_void_p(out[k])) for k in range(n)]
+
+    def close(self):
+        if self.h:
+            LIB.rtx_comm_destroy(self.h); self.h = None
+
+    def render_gathered(self, scene, cam, d_frame, d_hit_frame=0, max_depth=5, flags=0, stream=0, stats=False):
+        fc = Scene.flat_camera(cam)
+        st = Stats() if stats else None
+        rc = LIB.rtx_render_gathered(self.h, scene.h, C.byref(fc), max_depth, flags, C.c_void_p(d_frame),
+                                     C.c_void_p(d_hit_frame) if d_hit_frame else None,
+                                     C.c_void_p(stream) if stream else None, C.byref(st) if stats else None)
+        self.ctx._check(rc)
+        return st
+
+    def wait(self, stream=0):
+        self.ctx._check(LIB.rtx_comm_wait(self.h, C.c_void_p(stream) if stream else None))
+
+
+def render_multi(comms, scenes, cam, max_depth=5, flags=0, want_hit=True, want_stats=False):
+    """rtx_render_multi: one host thread, N GPUs -> host image."""
+    n = len(comms)
+    fc = Scene.flat_camera(cam)
+    ch = (C.c_void_p * n)(*[c.h for c in comms]); sh = (C.c_void_p * n)(*[s.h for s in scenes])
+    rgb = np.zeros((cam.vsize, cam.hsize, 3), np.uint8)
+    hit = np.full((cam.vsize, cam.hsize), -2, np.int32) if want_hit else None
+    st = Stats() if want_stats else None
+    rc = LIB.rtx_render_multi(ch, sh, n, C.byref(fc), max_depth, flags, rgb.ctypes.data_as(C.POINTER(C.c_uint8)),
+                              hit.ctypes.data_as(C.POINTER(C.c_int32)) if want_hit else None, C.byref(st) if want_stats else None)
+    comms[0].ctx._check(rc)
+    return dict(rgb=rgb, hit=hit, stats=st)
+
+
+def band_deinterleave(gathered, n_ranks, width, height, bpp=3):
+    """rtx_band_deinterleave (host): gathered compact band buffers of all ranks -> row-major frame."""
+    g = np.ascontiguousarray(gathered, np.uint8).ravel()
+    assert g.size == n_ranks * LIB.rtx_band_rows_padded(height, n_ranks) * width * bpp
+    out = np.zeros(height * width * bpp, np.uint8)
+    rc = LIB.rtx_band_deinterleave(g.ctypes.data_as(C.POINTER(C.c_uint8)), n_ranks, width, height, bpp, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc != OK:
+        raise RtxError(rc, "rtx_band_deinterleave")
+    return out.reshape(height, width, bpp)
 
 
 def load_yaml(text, max_cameras=8):

@@ -37,6 +37,11 @@ def _worker(rank, world, port, height, width, out_dir):
     gathered = torch.zeros((world, pad, width, 3), dtype=torch.uint8)
     dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
     full = b.deinterleave(gathered, height)
+    # the C ABI's host-side de-interleave (rtx_band_deinterleave / rtx_band_rows_padded: the row mapping the device
+    # kernel of rtx_render_gathered uses) must give the same frame
+    import rtx
+    assert rtx.LIB.rtx_band_rows_padded(height, world) == pad
+    assert np.array_equal(rtx.band_deinterleave(gathered.numpy(), world, width, height), full.numpy())
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
     dist.barrier(); dist.destroy_process_group()
 
@@ -54,6 +59,16 @@ def test_banded_frame_equals_single_rank(tmp_path, world):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert np.array_equal(got, ref)
+
+
+def test_c_abi_deinterleave_matches_python():
+    import rtx
+    rng = np.random.default_rng(7)
+    for h, w, n, bpp in ((52, 64, 2, 3), (100, 33, 3, 3), (8, 5, 4, 3), (2160, 16, 8, 4), (17, 9, 1, 3)):
+        pad = bands.rows_padded(h, n)
+        assert rtx.LIB.rtx_band_rows_padded(h, n) == pad
+        g = rng.integers(0, 256, (n, pad, w, bpp), dtype=np.uint8)
+        assert np.array_equal(rtx.band_deinterleave(g, n, w, h, bpp), bands.deinterleave(g, h))
 
 
 def test_band_bookkeeping():

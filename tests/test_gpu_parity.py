@@ -532,3 +532,142 @@ def test_render_device_writes_device_buffers_on_the_callers_stream(ctx):
         for b in bufs:
             hip.lib.hipFree(b)
         hip.lib.hipStreamDestroy(st)
+
+
+def test_multi_gpu_entry_points_with_a_one_rank_communicator(ctx, tmp_path):
+    """The C-ABI multi-GPU render (rtx_comm_* / rtx_render_gathered / rtx_render_multi, `rtx --gpus N`): bands of rank r of N,
+    ONE ncclAllGather (RCCL, opened by the library itself), de-interleave kernel.  The box has one GPU, so the communicator
+    has one rank: the same calls, the gather degenerates to RCCL's own copy.  Three frames in a row (the two internal
+    buffer sets alternate; sizes change, so the buffers regrow) must equal rtx_render byte for byte, ids included."""
+    import ctypes as C
+    import os
+    import subprocess
+    from PIL import Image
+    import rtx
+    hip = _Hip()
+    comm = rtx.Comm(ctx, rtx.comm_unique_id(), 0, 1)
+    assert rtx.LIB.rtx_comm_rank(comm.h) == 0 and rtx.LIB.rtx_comm_size(comm.h) == 1
+    st = C.c_void_p()
+    assert hip.lib.hipStreamCreate(C.byref(st)) == 0
+    bufs = []
+    try:
+        for name, w, h in (("S4", 333, 171), ("S1", 64, 32), ("S5", 640, 360)):
+            pw, pc = rtx.load_yaml(parity.scene_text(name, w, h))
+            sc = ctx.scene(pw)
+            try:
+                want = sc.render(pc[0], 5)
+                frame = hip.malloc(h * w * 3, 0x33); ids = hip.malloc(h * w * 4, 0x44)
+                bufs += [frame, ids]
+                stats = comm.render_gathered(sc, pc[0], frame.value, ids.value, 5, stream=st.value, stats=(name == "S4"))
+                comm.wait()                                         # host waits for gather + de-interleave
+                assert np.array_equal(hip.to_host(frame, h * w * 3, np.uint8).reshape(h, w, 3), want["rgb"]), name
+                assert np.array_equal(hip.to_host(ids, h * w * 4, np.int32).reshape(h, w), want["hit"]), name
+                if stats is not None:
+                    assert stats.rays == want["stats"].rays
+                # stream-level wait: a copy queued on the caller's stream behind rtx_comm_wait sees the finished frame
+                frame2 = hip.malloc(h * w * 3, 0x55); bufs.append(frame2)
+                comm.render_gathered(sc, pc[0], frame2.value, 0, 5, stream=st.value)
+                comm.wait(st.value)
+                assert hip.lib.hipStreamSynchronize(st) == 0
+                assert np.array_equal(hip.to_host(frame2, h * w * 3, np.uint8).reshape(h, w, 3), want["rgb"]), name
+            finally:
+                sc.close()
+    finally:
+        comm.close()
+        for b in bufs:
+            hip.lib.hipFree(b)
+        hip.lib.hipStreamDestroy(st)
+    # one host thread, "all" GPUs of the box (ncclCommInitAll + grouped all-gather)
+    comms = rtx.Comm.init_all([ctx])
+    try:
+        pw, pc = rtx.load_yaml(parity.scene_text("S4", 200, 100))
+        sc = ctx.scene(pw)
+        want = sc.render(pc[0], 5)
+        got = rtx.render_multi(comms, [sc], pc[0], 5, want_stats=True)
+        assert np.array_equal(got["rgb"], want["rgb"]) and np.array_equal(got["hit"], want["hit"])
+        assert got["stats"].rays == want["stats"].rays
+        sc.close()
+    finally:
+        for c in comms:
+            c.close()
+    # the CLI: rtx <scene> --gpus 1 writes the same PNG as the single-GPU path
+    text = parity.scene_text("S1", 96, 48)
+    scene = tmp_path / "multi.yaml"
+    scene.write_text(text)
+    exe = os.path.join(os.path.dirname(rtx.LIB_PATH), "rtx")
+    subprocess.run([exe, str(scene), "--gpus", "1"], check=True, timeout=200, cwd=str(tmp_path))
+    pw, pc = rtx.load_yaml(text)
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "multi.png"))), ctx.render(pw, pc[0], 5)["rgb"])
+
+
+def test_async_overflow_is_sticky_not_silent(ctx):
+    """include/rtx.h: an asynchronous render cannot return a device-side RTX_E_CAPACITY itself; the condition must be
+    sticky: refused by the next render call, returned and cleared by rtx_ctx_poll.  Provoked with the split guard: at
+    max_depth 8 with split tiles forced and a guard of 1 wave iteration (debug option) every split wave gives up."""
+    import ctypes as C
+    import rtx
+    hip = _Hip()
+    pw, pc = rtx.load_yaml(parity.scene_text("S4", 320, 200))
+    sc = ctx.scene(pw)
+    buf = hip.malloc(200 * 320 * 3, 0)
+    try:
+        ctx.options(lpt=1, split=1, split_class=1, debug=2)         # debug=2: split guard of one iteration
+        assert sc.render_device(pc[0], buf.value, 0, 5) is None     # queued; the launch trips the guard
+        with pytest.raises(rtx.RtxError) as e:
+            ctx.poll(wait=True)
+        assert e.value.code == rtx.E_CAPACITY
+        ctx.poll(wait=True)                                         # cleared
+        sc.render_device(pc[0], buf.value, 0, 5)
+        assert rtx.LIB.rtx_ctx_poll(ctx.h, 1) == rtx.E_CAPACITY     # still reported when nobody asked in between ...
+        sc.render_device(pc[0], buf.value, 0, 5)
+        hip.lib.hipDeviceSynchronize()
+        with pytest.raises(rtx.RtxError):                           # ... and the next call refuses to queue more work
+            sc.render_device(pc[0], buf.value, 0, 5)
+        assert rtx.LIB.rtx_ctx_poll(ctx.h, 1) == rtx.E_CAPACITY
+        with pytest.raises(rtx.RtxError) as e:                      # the synchronous path names the cause
+            sc.render(pc[0], 5)
+        assert e.value.code == rtx.E_CAPACITY and "guard" in str(e.value)
+        ctx.options(debug=0)
+        ok = sc.render(pc[0], 5)                                    # with the real guard the same frame renders
+        ctx.options(lpt=-1, split=-1, split_class=6)
+        assert np.array_equal(ok["rgb"], sc.render(pc[0], 5)["rgb"])
+    finally:
+        ctx.options(lpt=-1, split=-1, split_class=6, debug=0)
+        rtx.LIB.rtx_ctx_poll(ctx.h, 1)
+        sc.close()
+        hip.lib.hipFree(buf)
+
+
+def test_gathered_render_inside_a_pytorch_process(tmp_path):
+    """bench.py's N > 1 configuration: PyTorch-ROCm initialises the GPU first (its own HIP runtime and RCCL are then the
+    ones in the process), the library opens RCCL itself (the copy already loaded) and gathers into a torch tensor.  One
+    rank here (one GPU); run in a child process so torch's runtime does not leak into the other tests."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+import torch
+torch.cuda.init(); dev = torch.device("cuda", 0); torch.zeros(1, device=dev)
+import parity, rtx
+ctx = rtx.Context(0)
+comm = rtx.Comm(ctx, rtx.comm_unique_id(), 0, 1)
+pw, pc = rtx.load_yaml(parity.scene_text("S4", 333, 171))
+sc = ctx.scene(pw)
+want = sc.render(pc[0], 5)
+s = torch.cuda.Stream(device=dev)
+frames = [torch.zeros(171 * 333 * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+for k in range(4):
+    comm.render_gathered(sc, pc[0], frames[k & 1].data_ptr(), 0, 5, 0, s.cuda_stream)
+comm.wait()
+for f in frames:
+    assert np.array_equal(f.cpu().numpy().reshape(171, 333, 3), want["rgb"])
+sc.close(); comm.close(); ctx.close()
+print("ok")
+'''
+    import os
+    env = dict(os.environ)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env["PYTHONPATH"] = os.pathsep.join([here, os.path.join(here, "..", "ray-tracer_amd", "python"), os.path.join(here, "..", "tools")])
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
