@@ -117,7 +117,7 @@ void cull_sphere(const double* inverse16, const double* lc, double lr, float* ou
 
 // compile-time view of one op (head + body); split into the two device arrays at upload
 struct OpRec {
-    int32_t kind, level, skip, flags, shape, clevel;
+    int32_t kind, level, skip, flags, shape, clevel, xf;
     float cull[4];
     double inv[12], w33, bounds[6];
 };
@@ -130,6 +130,7 @@ struct Compiler {
     std::vector<int32_t> stack;      // op indices of the ancestors (root first)
     std::vector<char> seen;
     int max_container_level = -1;
+    int org_depth = 0, dir_depth = 0, max_org = 0, max_dir = 0;   // LDS slots along the current path / maxima
     bool has_csg = false;
     int max_csg_entries = 0;
     int err = RTX_OK;
@@ -144,6 +145,11 @@ struct Compiler {
             if (!affine_rows(d->node_inverse + (size_t)node * 16, o.inv, &o.w33))
                 bad(RTX_E_UNSUPPORTED, "node " + std::to_string(node) + ": transform is not affine");
             if (!(o.w33 == 1.0)) o.flags |= OPF_DIV;
+            // XF_* class from the exact bits of the inverse (rows 0..2 + w33)
+            bool lin_id = o.w33 == 1.0;
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) lin_id = lin_id && (o.inv[r * 4 + c] == (r == c ? 1.0 : 0.0));
+            const bool t0 = o.inv[3] == 0.0 && o.inv[7] == 0.0 && o.inv[11] == 0.0;
+            o.xf = !lin_id ? XF_GENERAL : (t0 ? XF_IDENTITY : XF_TRANSLATE);
             if (d->node_bounds) std::memcpy(o.bounds, d->node_bounds + (size_t)node * 6, sizeof o.bounds);
         }
         o.cull[0] = o.cull[1] = o.cull[2] = 0.f; o.cull[3] = INFINITY;
@@ -203,7 +209,11 @@ struct Compiler {
             const int b = (int)ops.size();
             ops.push_back(make(node, OPK_GROUP_BEGIN, level, lf, clevel));
             stack.push_back(b);
+            const int xf = ops[b].xf;
+            org_depth += xf != XF_IDENTITY; dir_depth += xf == XF_GENERAL;
+            max_org = std::max(max_org, org_depth); max_dir = std::max(max_dir, dir_depth);
             for (int i = 0; i < nc; i++) entries += emit(d->children[fc + i], level + 1, list, clevel + 1);
+            org_depth -= xf != XF_IDENTITY; dir_depth -= xf == XF_GENERAL;
             stack.pop_back();
             if (list) ops.push_back(make(-1, OPK_GROUP_END, level, lf, clevel));   // outside CSG an END has nothing to do
             ops[b].skip = (int)ops.size();
@@ -220,9 +230,13 @@ struct Compiler {
             OpRec ob = make(node, OPK_CSG_BEGIN, level, f, cl); ob.shape = cop;
             ops.push_back(ob);
             stack.push_back(b);
+            const int xf = ob.xf;
+            org_depth += xf != XF_IDENTITY; dir_depth += xf == XF_GENERAL;
+            max_org = std::max(max_org, org_depth); max_dir = std::max(max_dir, dir_depth);
             entries += emit(d->children[fc], level + 1, true, cl + 1);
             OpRec om = make(-1, OPK_CSG_MID, level, f, cl); om.shape = cop; ops.push_back(om);
             entries += emit(d->children[fc + 1], level + 1, true, cl + 1);
+            org_depth -= xf != XF_IDENTITY; dir_depth -= xf == XF_GENERAL;
             stack.pop_back();
             OpRec oe = make(-1, OPK_CSG_END, level, f, cl); oe.shape = cop; ops.push_back(oe);
             ops[b].skip = (int)ops.size();
@@ -285,7 +299,8 @@ struct ListBuilder {
                     r.op = op; r.skip = o.skip; r.list = -1;
                     bool ok = true;
                     for (int b = 0; b < 6; b++) ok = ok && (std::isinf(o.bounds[b]) || std::fabs(o.bounds[b]) <= 1e100);
-                    r.flags = ((o.flags & OPF_DIV) ? CONT_DIV : 0) | (ok ? 0 : CONT_NOFILTER) | (o.kind == OPK_CSG_BEGIN ? CONT_CSG : 0);
+                    r.flags = ((o.flags & OPF_DIV) ? CONT_DIV : 0) | (ok ? 0 : CONT_NOFILTER) | (o.kind == OPK_CSG_BEGIN ? CONT_CSG : 0) |
+                              (o.xf << CONT_XF_SHIFT);
                     if (o.kind == OPK_GROUP_BEGIN) groups.push_back({(int)conts.size(), op});
                     conts.push_back(r);
                 } else if (o.flags & OPF_INLINE) {
@@ -301,6 +316,8 @@ struct ListBuilder {
         for (auto& g : groups) {
             const int li = build(g.second + 1, ops[g.second].skip);     // (no END op is emitted outside CSG)
             conts[g.first].list = li;
+            static_assert(sizeof(ListChunk) == sizeof conts[0].child_hdr, "ContRec carries one ListChunk");
+            std::memcpy(conts[g.first].child_hdr, &chunks[li], sizeof(ListChunk));
         }
         return first;
     }
@@ -511,6 +528,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
             bool ok = true;
             for (int k = 0; k < 6; k++) ok = ok && (std::isinf(o.bounds[k]) || std::fabs(o.bounds[k]) <= 1e100);   // NaN fails both
             if (!ok) h.info |= 1u << 24;
+            h.info |= (uint32_t)o.xf << 25;
         }
         h.skip = o.skip; h.shape = o.shape;
         std::memcpy(h.cull, o.cull, sizeof h.cull);
@@ -561,7 +579,8 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
-    s->dev.n_levels = cc.max_container_level + 2;   // slot 0 = world ray, slot L + 1 = local ray of the level-L container
+    s->dev.n_levels = cc.max_container_level + 2;
+    s->dev.n_org_slots = cc.max_org + 1; s->dev.n_dir_slots = cc.max_dir + 1;   // slot 0 = the ray being traced
     s->dev.csg_entries = cc.max_csg_entries; s->dev.has_csg = cc.has_csg ? 1 : 0; s->dev.has_transparency = transp ? 1 : 0; s->dev.has_branching = secondary ? 1 : 0;
     *out = s;
     return RTX_OK;

@@ -43,7 +43,12 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
 #define OPH_FLAGS(i) ((int)(((i) >> 4) & 15u))
 #define OPH_LEVEL(i) ((int)(((i) >> 8) & 255u))
 #define OPH_CLEVEL(i) ((int)(((i) >> 16) & 255u))
-#define OPH_NOFILTER(i) ((int)(((i) >> 24) & 1u))   // container bounds unsuitable for the interval filter (NaN or |finite| > 1e100)
+#define OPH_NOFILTER(i) ((int)(((i) >> 24) & 1u))
+#define OPH_XF(i) ((int)(((i) >> 25) & 3u))         // containers: XF_* class of the inverse transform
+// class of a container's inverse transform (decided on the host from its exact bits): what entering it does to a ray
+enum { XF_GENERAL = 0,     // any affine map: origin and direction change
+       XF_TRANSLATE = 1,   // linear part exactly the identity, w33 == 1: the direction is unchanged, origin = p + t
+       XF_IDENTITY = 2 };  // ... and t == 0: the ray is unchanged (CSG operands without a transform of their own)   // container bounds unsuitable for the interval filter (NaN or |finite| > 1e100)
 struct OpBody {
     double inv[12];    // rows 0..2 of inverse(transform): inv[r*4+c]
     double w33;        // inverse(3,3)
@@ -68,7 +73,7 @@ struct ListChunk {           // 32 bytes = one s_load_dwordx8
     int32_t cont_base;       // cont_recs[cont_base + r] = r-th container child of this chunk
 };
 #define LIST_KINDS_SHIFT 0
-struct ContRec {             // 192 bytes: everything a visit of a container child needs, one scalar round trip
+struct __attribute__((aligned(32))) ContRec {   // 224 bytes: everything a visit of a container child needs, one scalar round trip
     double inv[12];          // rows 0..2 of inverse(transform)
     double w33;
     double bounds[6];
@@ -77,8 +82,11 @@ struct ContRec {             // 192 bytes: everything a visit of a container chi
     int32_t skip;            // op index past the container (range of a CSG root for the op interpreter)
     int32_t list;            // first chunk of its child list (groups), -1 for a CSG root
     int32_t flags;           // CONT_*
+    uint32_t pad0[2];
+    uint32_t child_hdr[8];   // groups: copy of the ListChunk `list` points at (the descent needs no second round trip)
 };
-enum { CONT_DIV = 1, CONT_NOFILTER = 2, CONT_CSG = 4 };
+enum { CONT_DIV = 1, CONT_NOFILTER = 2, CONT_CSG = 4, CONT_XF_SHIFT = 4 };
+#define CONT_XF(f) (((f) >> CONT_XF_SHIFT) & 3)
 struct ChunkCounts { int32_t spheres, planes, cubes, containers; };   // per chunk, for the event counters
 
 // per ShapeIndex (host side only, while compiling)
@@ -126,7 +134,8 @@ struct SceneDev {
     const int32_t* path_ops;
     const MaterialRec* materials;
     const LightRec* lights;
-    int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = LDS ray-stack slots needed
+    int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = deepest list level + 1
+    int32_t n_org_slots, n_dir_slots;              // LDS ray stack: origin / direction slots needed (rtx_kernel.hip)
     int32_t has_csg, has_transparency;
     int32_t csg_entries, has_branching;  // has_branching: some material is reflective AND transparent (two children per hit)  // largest number of list entries a CSG root can produce (LDS list area per lane)
 };

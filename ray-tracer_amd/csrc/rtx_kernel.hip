@@ -50,7 +50,7 @@ DI V3 normalize3(V3 a) { return a / norm3(a); }            // unscale: component
 DI V3 reflect3(V3 v, V3 n) { return v - n * 2.0 * dot3(v, n); }   // geometry.rs:49-51
 
 #define INF __builtin_inf()
-#define LDS_SLOT_DOUBLES 384           // one ray per lane: 6 x 64 doubles
+#define LDS_HALF_DOUBLES 192           // one origin OR one direction per lane: 3 x 64 doubles
 #define CULL_KAPPA 1.0e-5f             // relative slack on |oc|^2 covering f32 rounding of the pre-test
 
 // Projective3 * Point3 with an affine matrix: (M3x3 p + t) / w33   (rows m[r*4+c])
@@ -289,7 +289,16 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     const unsigned wt_start = (unsigned)__builtin_amdgcn_s_memrealtime();
     int wt_class = 0;
 #endif
-    extern __shared__ double lds_rays[];   // [slot][6][64]: slot 0 = the ray being traced, slot L+1 = local ray inside the level-L container
+    // LDS ray stack: origin slots [n_org][3][64] then direction slots [n_dir][3][64].  Origin / direction slot 0 = the ray being
+    // traced; a container's children get a NEW origin slot unless its transform is the identity, and a NEW direction slot only
+    // if the transform has a linear part (rtx_device.h: XF_*): a pure translation leaves the direction as it is and the identity
+    // leaves the whole ray, so those levels share their parent's slots (nested translated groups: 1.5 KB per level, not 3 KB).
+    // slotmap: lane L holds (origin slot | direction slot << 8) of list level L (a VGPR used as a wave-uniform array)
+    extern __shared__ double lds_rays[];
+    double* const org_base = lds_rays + threadIdx.x;
+    double* const dir_base = lds_rays + sc.n_org_slots * LDS_HALF_DOUBLES + threadIdx.x;
+    double* const lds_after = lds_rays + (sc.n_org_slots + sc.n_dir_slots) * LDS_HALF_DOUBLES;
+    int slotmap = 0;
     const int lane = threadIdx.x;
     int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
     constexpr int S = SPLIT ? RTX_SPLIT_BITS : 0;   // log2 waves per tile
@@ -390,8 +399,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         V3 pixel = xf_point(cam.inv, cam.w33, cam.div != 0, V3{world_x, world_y, -1.0});
         V3 ro = V3{cam.origin[0], cam.origin[1], cam.origin[2]};
         V3 rd = normalize3(pixel - ro);
-        double* s = lds_rays + lane;
-        s[0] = ro.x; s[64] = ro.y; s[128] = ro.z; s[192] = rd.x; s[256] = rd.y; s[320] = rd.z;
+        org_base[0] = ro.x; org_base[64] = ro.y; org_base[128] = ro.z;
+        dir_base[0] = rd.x; dir_base[64] = rd.y; dir_base[128] = rd.z;
     }
     // Canvas::write_pixel + Color::to_rgb (canvas.rs:31-33, color.rs:40-48), the moment a lane's colour is final
     auto write_pixel = [&](double r, double g, double b) {
@@ -419,14 +428,14 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     // CSG hit list (per lane)
     // (in LDS, after the ray slots: entry e of this lane at [e * 64 + lane]; sized by the scene's largest CSG
     // root.  In scratch, every step of the merge loops was a dependent round trip to memory.)
-    double* const lt_ = lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + lane;
-    uint32_t* const ls_ = (uint32_t*)(lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + sc.csg_entries * 64) + lane;
+    double* const lt_ = lds_after + lane;
+    uint32_t* const ls_ = (uint32_t*)(lds_after + sc.csg_entries * 64) + lane;
 #define lt(i) lt_[(i) * 64]
 #define ls(i) ls_[(i) * 64]
     // split mailboxes (after the CSG lists): colour [3][64] indexed by the SENDER's lane + a posted flag per lane.
     // A lane posts at most once (then it retires), so one box per lane is enough for all levels.
     // mb_state: 0 free, 1 a task is running on this lane, 2 its colour is posted and not yet taken
-    volatile double* const mb_ = lds_rays + sc.n_levels * LDS_SLOT_DOUBLES + (sc.csg_entries * 64 * 12 + 7) / 8;
+    volatile double* const mb_ = lds_after + (sc.csg_entries * 64 * 12 + 7) / 8;
     volatile int* const mb_state = (volatile int*)(mb_ + 3 * 64);
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
@@ -488,14 +497,43 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         int cached_level = -1;
         auto sync_level = [&](int level) {
             if (level == cached_level) return;
-            const double* s = lds_rays + level * LDS_SLOT_DOUBLES + lane;
-            po = V3{s[0], s[64], s[128]}; pd = V3{s[192], s[256], s[320]};
+            const int sm = __builtin_amdgcn_readlane(slotmap, level);
+            const double* so = org_base + (sm & 0xff) * LDS_HALF_DOUBLES;
+            const double* sd = dir_base + (sm >> 8) * LDS_HALF_DOUBLES;
+            po = V3{so[0], so[64], so[128]}; pd = V3{sd[0], sd[64], sd[128]};
             fox = (float)po.x; foy = (float)po.y; foz = (float)po.z;
             fdx = (float)pd.x; fdy = (float)pd.y; fdz = (float)pd.z;
             fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
             cached_level = level;
         };
         sync_level(0);
+        // the lanes that pass a container's bounds test enter it: the children (level + 1) walk in the container's space.
+        // xf: XF_GENERAL / XF_TRANSLATE / XF_IDENTITY (host-classified from the inverse); the caller has put the local
+        // ray into po / pd (only the parts that change: pd is untouched unless XF_GENERAL, po unless not XF_IDENTITY)
+        auto enter_level = [&](int level, int xf, bool pass) {
+            const int sm = __builtin_amdgcn_readlane(slotmap, level);
+            const int os = (sm & 0xff) + (xf != XF_IDENTITY ? 1 : 0), ds = (sm >> 8) + (xf == XF_GENERAL ? 1 : 0);
+            if (lane == level + 1) slotmap = os | (ds << 8);
+            if (xf != XF_IDENTITY) {
+                fox = (float)po.x; foy = (float)po.y; foz = (float)po.z;
+                if (pass) { double* s = org_base + os * LDS_HALF_DOUBLES; s[0] = po.x; s[64] = po.y; s[128] = po.z; }
+            }
+            if (xf == XF_GENERAL) {
+                fdx = (float)pd.x; fdy = (float)pd.y; fdz = (float)pd.z;
+                fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+                if (pass) { double* s = dir_base + ds * LDS_HALF_DOUBLES; s[0] = pd.x; s[64] = pd.y; s[128] = pd.z; }
+            }
+            cached_level = level + 1;
+        };
+        // ray into a container's space (object_store.rs:244-246, rays.rs:21-23).  A translation's inverse has the identity as
+        // its linear part: the direction is unchanged and the origin is p + t (the products by 1 and the sums with products
+        // by 0 of the general formula change nothing but the sign of a zero, which no later operation can observe: zeros of
+        // ray components are only ever added, multiplied and compared, never divided by); the identity changes nothing.
+        auto into_container = [&](const auto* inv, double w33, bool div, int xf, V3& lo, V3& ld) {
+            if (xf == XF_GENERAL) { lo = xf_point(inv, w33, div, po); ld = xf_vector(inv, pd); }
+            else if (xf == XF_TRANSLATE) { lo = V3{po.x + inv[3], po.y + inv[7], po.z + inv[11]}; ld = pd; }
+            else { lo = po; ld = pd; }
+        };
 
         // ---- the op interpreter: walks the ops [cur, end) of ONE CSG root in program order (hit lists need
         // the reference's order); everything outside CSG goes through the child lists below
@@ -616,8 +654,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 } else {
                     // ---- Groups::local_intersect (group.rs:64-75) / CSGs::local_intersect (csg.rs:73-78)
                     const AS4 OpBody* op = bodies + cur;
-                    V3 lo = xf_point(op->inv, op->w33, (flags & OPF_DIV) != 0, po);
-                    V3 ld = xf_vector(op->inv, pd);
+                    const int xf = OPH_XF(H_INFO(h));
+                    V3 lo, ld;
+                    into_container(op->inv, op->w33, (flags & OPF_DIV) != 0, xf, lo, ld);
                     if (test) EV(RTX_EV_X_XFORM, 1);
                     // decision by the interval filter; the exact slab test (six divisions) only where a lane is undecided
                     const int fdec = OPH_NOFILTER(H_INFO(h)) ? -1
@@ -637,18 +676,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     } else {
                         // the children (level + 1) walk in this node's space
                         po = lo; pd = ld;
-                        fox = (float)lo.x; foy = (float)lo.y; foz = (float)lo.z;
-                        fdx = (float)ld.x; fdy = (float)ld.y; fdz = (float)ld.z;
-                        fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
-                        cached_level = level + 1;
+                        enter_level(level, xf, pass);
                         if (pass) {
-                            double* s = lds_rays + (level + 1) * LDS_SLOT_DOUBLES + lane;
-                            s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
-                            s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
-                            {
-                                const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
-                                starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
-                            }
+                            const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
+                            starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                         }
                     }
                 }
@@ -741,7 +772,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             int level = 0, chunk = 0;
             unsigned U = 0;
             bool fresh = true;
-            int stk_chunk = 0, stk_U = 0;
+            int stk_chunk = 0, stk_U = 0, stk_cm = 0, stk_next = 0, stk_cb = 0;
+            bool have_hdr = false;                                 // hdr already holds the fresh chunk's header (it came with the ContRec)
             Head hdr = load_head((const AS4 OpHead*)chunks);       // ListChunk has the size of a head: 8 dwords
             for (;;) {
                 level = __builtin_amdgcn_readfirstlane(level);
@@ -752,7 +784,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 if (fresh) {
                     fresh = false;
                     U = 0;
-                    hdr = load_head((const AS4 OpHead*)(chunks + chunk));
+                    if (!have_hdr) hdr = load_head((const AS4 OpHead*)(chunks + chunk));
+                    have_hdr = false;
                     if (__any(act)) {
                         TM(tm_other);
                         const int n = (int)hdr[0], child_base = (int)hdr[1], op0 = (int)hdr[6];
@@ -877,8 +910,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         if (cull_miss(ch, fox, foy, foz, fdx, fdy, fdz, fdd)) test = false;
                     }
                     if (__any(test)) {
-                        V3 lo = xf_point(cr->inv, cr->w33, (cflags & CONT_DIV) != 0, po);
-                        V3 ld = xf_vector(cr->inv, pd);
+                        const int xf = CONT_XF(cflags);
+                        V3 lo, ld;
+                        into_container(cr->inv, cr->w33, (cflags & CONT_DIV) != 0, xf, lo, ld);
                         if (test) EV(RTX_EV_X_XFORM, 1);
                         // decision by the interval filter; the exact slab test (six divisions) only where a lane is undecided
                         const int fdec = (cflags & CONT_NOFILTER) ? -1
@@ -895,19 +929,14 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         if (__any(pass)) {
                             // the children (level + 1) walk in this group's space
                             po = lo; pd = ld;
-                            fox = (float)lo.x; foy = (float)lo.y; foz = (float)lo.z;
-                            fdx = (float)ld.x; fdy = (float)ld.y; fdz = (float)ld.z;
-                            fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
-                            cached_level = level + 1;
-                            if (pass) {
-                                double* s = lds_rays + (level + 1) * LDS_SLOT_DOUBLES + lane;
-                                s[0] = lo.x; s[64] = lo.y; s[128] = lo.z;
-                                s[192] = ld.x; s[256] = ld.y; s[320] = ld.z;
-                                alive = level + 1;
-                            }
-                            if (lane == level) { stk_chunk = chunk; stk_U = (int)U; }      // lane-indexed uniform arrays
+                            enter_level(level, xf, pass);
+                            if (pass) alive = level + 1;
+                            // lane-indexed uniform arrays: what the walk needs of this chunk when it comes back (no header reload)
+                            if (lane == level) { stk_chunk = chunk; stk_U = (int)U; stk_cm = (int)hdr[4]; stk_next = (int)hdr[5]; stk_cb = (int)hdr[7]; }
                             level = level + 1;
                             chunk = cr->list;
+                            hdr = *(const AS4 Head*)cr->child_hdr;     // the first chunk of the child list travels with the record
+                            have_hdr = true;
                             fresh = true;
                         }
                     }
@@ -920,7 +949,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 level = level - 1;
                 chunk = __builtin_amdgcn_readlane(stk_chunk, level);
                 U = (unsigned)__builtin_amdgcn_readlane(stk_U, level);
-                hdr = load_head((const AS4 OpHead*)(chunks + chunk));
+                hdr[4] = (uint32_t)__builtin_amdgcn_readlane(stk_cm, level);
+                hdr[5] = (uint32_t)__builtin_amdgcn_readlane(stk_next, level);
+                hdr[7] = (uint32_t)__builtin_amdgcn_readlane(stk_cb, level);
             }
         }
 
@@ -956,8 +987,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 hmat = hr.material;
                 EV(RTX_EV_LEVELS, hr.path_len + 1);
                 {
-                    const double* w = lds_rays + lane;      // the ray just traced
-                    const V3 wo = {w[0], w[64], w[128]}, wd = {w[192], w[256], w[320]};
+                    // the ray just traced
+                    const V3 wo = {org_base[0], org_base[64], org_base[128]}, wd = {dir_base[0], dir_base[64], dir_base[128]};
                     hp = wo + wd * best_t;      // rays.rs:17-19 (t * direction is commutative)
                     eyev = neg(wd);
                 }
@@ -1162,7 +1193,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         pend &= pend - 1u;
                         Frame& f = frames[level];
                         double* hs = lds_rays + target;            // the helper's ray slot 0
-                        hs[0] = f.o2[0]; hs[64] = f.o2[1]; hs[128] = f.o2[2]; hs[192] = f.d2[0]; hs[256] = f.d2[1]; hs[320] = f.d2[2];
+                        double* hd = lds_rays + sc.n_org_slots * LDS_HALF_DOUBLES + target;
+                        hs[0] = f.o2[0]; hs[64] = f.o2[1]; hs[128] = f.o2[2]; hd[0] = f.d2[0]; hd[64] = f.d2[1]; hd[128] = f.d2[2];
                         mb_rem[target] = f.remaining - 1;
                         // (the helper reads its ray slot with plain loads: order the stores above before the flag, and see
                         // the acquire fence at the top of the trace)
@@ -1255,8 +1287,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 
         // the next ray goes to LDS slot 0, where the traversal and the next shade read it
         if (newray) {
-            double* s = lds_rays + lane;
-            s[0] = nro.x; s[64] = nro.y; s[128] = nro.z; s[192] = nrd.x; s[256] = nrd.y; s[320] = nrd.z;
+            org_base[0] = nro.x; org_base[64] = nro.y; org_base[128] = nro.z;
+            dir_base[0] = nrd.x; dir_base[64] = nrd.y; dir_base[128] = nrd.z;
         }
     }
 
@@ -1352,7 +1384,7 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
     if (blocks <= 0) return hipSuccess;
     const bool split = !rp->probe && rp->use_lists && rp->split_cap > 0 && rp->split_launch;
     if (split) blocks = rp->split_cap << RTX_SPLIT_BITS;
-    size_t lds = (size_t)sc->n_levels * LDS_SLOT_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 7) & ~(size_t)7);
+    size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 7) & ~(size_t)7);
     if (split) lds += 64 * (3 * sizeof(double) + 2 * sizeof(int));
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
