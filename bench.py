@@ -185,7 +185,7 @@ def main():
         counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_secondary,
                                flops.frame_flops(evs, st.rays_primary, st.rays_shadow, nl),
                                flops.executed_flops(evs, st.rays_primary, st.rays_shadow, nl),
-                               evs["cull"], evs["x_xform"], evs["xform"], evs["backface"]], dtype=torch.float64, device=dev)
+                               evs["cull"], evs["x_xform"], evs["xform"], st.rays_shadow_skipped], dtype=torch.float64, device=dev)
         if N > 1:
             all_reduce(counts)
         rays_frame = int(counts[0] + counts[1] + counts[2])
@@ -254,7 +254,7 @@ def main():
                 "node_visits": {"reference_defined": int(counts[7]), "f32_pre_tests": int(counts[5]), "exact_f64_tests": int(counts[6])},
                 "executed": {"f64_tflops": executed, "frac_of_peak": executed / flops.FP64_VECTOR_PEAK_TFLOPS,
                              "frac_of_unfused_ceiling": executed / flops.FP64_UNFUSED_PEAK_TFLOPS}}
-        rays_traced = rays_frame - int(counts[8]) if flops.SKIPS_BACKFACE_SHADOW_RAYS else rays_frame
+        rays_traced = rays_frame - int(counts[8])
         return {"text": text, "width": width, "height": height, "desc": desc, "rays_frame": rays_frame, "elapsed": elapsed,
                 "value": rays_frame * steps / elapsed / 1e6, "ms_per_step": elapsed / steps * 1000.0,
                 "traced_mrays_per_s": rays_traced * steps / elapsed / 1e6, "rays_traced": rays_traced,
@@ -279,8 +279,7 @@ def main():
                           "rays_per_frame": m["rays_frame"], "rays": m["rays"], "parallelism": gather},
                "traced_rays": {"rays_per_frame": m["rays_traced"], "mrays_per_s": m["traced_mrays_per_s"],
                                "note": "rays the kernel really traces: shadow rays whose light is behind the surface (material.rs:67: the answer is "
-                                       "unused) are counted as the reference-defined rays they are but not traced" if flops.SKIPS_BACKFACE_SHADOW_RAYS
-                                       else "every reference-defined ray is traced"},
+                                       "unused) are counted as the reference-defined rays they are but not traced (rtx_stats.rays_shadow_skipped)"},
                "roofline": m["roofline"]}
     if N == 1 and not args.no_secondary and args.workload == "S4" and not args.width and not args.height:
         s3 = measure("S3", 0, 0, args.steps, args.warmup)

@@ -112,6 +112,9 @@ typedef struct rtx_stats {
     uint64_t ev[RTX_EV_COUNT];           /* filled only with RTX_F_COUNT_EVENTS */
     uint64_t overflow_pixels;            /* pixels that hit a bounded-list limit (then RTX_E_CAPACITY) */
     double   kernel_ms;                  /* hipEvent time of the launches of this render (tile-order probe, when used, + frame) */
+    uint64_t rays_shadow_skipped;        /* of rays_shadow: is_shadowed calls whose answer material.rs:67 ignores (the light is
+                                            behind the surface) — counted as the reference-defined rays they are, not traced.
+                                            rays traced = primary + secondary + shadow - this.  0 with RTX_F_NO_SHADOW_EARLY_OUT */
 } rtx_stats;
 
 /* render flags */

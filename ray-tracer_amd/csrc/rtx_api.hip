@@ -757,6 +757,7 @@ int fill_stats(rtx_ctx* ctx, const rtx_camera* cam, rtx_bands bands, const unsig
     stats->overflow_pixels = h[RTX_CNT_OVERFLOW] % RTX_GUARD_UNIT;
     for (int i = 0; i < RTX_EV_COUNT; i++) stats->ev[i] = h[RTX_CNT_EV0 + i];
     stats->kernel_ms = ms;
+    stats->rays_shadow_skipped = h[RTX_CNT_SKIPPED];
     if (h[RTX_CNT_OVERFLOW] >= RTX_GUARD_UNIT)
         return fail(ctx, RTX_E_CAPACITY, "a split-tile wave exceeded its iteration guard (pixels of that tile are unwritten)");
     if (stats->overflow_pixels) return fail(ctx, RTX_E_CAPACITY, "bounded CSG list overflowed on the device");

@@ -175,7 +175,8 @@ struct RenderParams {
 #define RTX_CNT_SHADOW 1
 #define RTX_CNT_OVERFLOW 2
 #define RTX_CNT_EV0 3
-#define RTX_CNT_TOTAL (3 + 24)
+#define RTX_CNT_SKIPPED (3 + 24)   /* shadow rays counted but not traced (light certainly behind the surface) */
+#define RTX_CNT_TOTAL (3 + 24 + 1)
 // The counters are replicated over RTX_CNT_SLOTS slots of RTX_CNT_STRIDE entries (256 bytes, own cache lines);
 // a wave adds into slot (block index mod RTX_CNT_SLOTS) and the host sums the slots.  With ONE set of
 // counters every wave's two ray-count atomics hit the same address and serialise at ~12 ns each: a floor of

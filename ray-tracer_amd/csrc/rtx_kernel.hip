@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     const int n_lights = sc.n_lights;
 
     // ---- per-lane counters
-    unsigned n_radiance = 0, n_shadow = 0, overflow = 0;
+    unsigned n_radiance = 0, n_shadow = 0, overflow = 0, n_skipped = 0;
     unsigned ev[RTX_EV_USED];             // reference-defined events + executed-work and occupancy diagnostics
     if (COUNT) {
 #pragma unroll
@@ -960,6 +960,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         bool returning = false;                 // lane has a finished colour to hand to its parent frame
         double rr = 0.0, rg = 0.0, rb = 0.0;
         bool lights_done = false;
+        bool shading = false;                   // the lane is at a hit whose lights are being evaluated
         double sr = 0.0, sg = 0.0, sb = 0.0;    // surface colour of the hit being shaded (this iteration's view)
         bool newray = false;                    // lane launches (nro, nrd) next
         V3 nro = {0, 0, 0}, nrd = {0, 0, 0};
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 n1op = c1s;
                 n2op = (c1s >= 0 && best_inside) ? ((hop == c1s) ? c2s : c1s) : hop;
                 light_k = 0;
-                if (n_lights == 0) lights_done = true;
+                shading = true;
             }
             TM(tm_prep);
         } else if (mode == MODE_SHADOW) {
@@ -1075,13 +1076,37 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             if (light_k > 0) { const Frame& f = frames[sp]; sr = f.s[0]; sg = f.s[1]; sb = f.s[2]; }
             sr = sr + cr; sg = sg + cg; sb = sb + cb;
             light_k++;
-            if (light_k >= n_lights) lights_done = true;
-            else { Frame& f = frames[sp]; f.s[0] = sr; f.s[1] = sg; f.s[2] = sb; }
+            shading = true;
             TM(tm_light);
         }
 
-        if (mode != MODE_DONE && !returning && !lights_done) {
+        if (shading) {
+            // ---- lights whose is_shadowed answer cannot matter: material.rs:67 ignores `in_shadow` when light_dot_normal < 0,
+            // so a light that is CERTAINLY behind the surface contributes its ambient term whatever the trace would say.
+            // Done at once for plain-coloured materials (the term is then three products); the is_shadowed call stays a
+            // counted ray (reference-defined work) but is not traced.  Sign test without the normalisation: (pos - point) .
+            // normal below a margin 1000x the rounding error of the exact expression => the exact ldn is negative too.
+            const MaterialRec* m = sc.materials + hmat;
+            if (!rp.no_early_out && m->kind == RTX_PAT_PLAIN) {
+                while (light_k < n_lights) {
+                    const LightRec* L = sc.lights + light_k;
+                    const V3 lv = V3{L->pos[0], L->pos[1], L->pos[2]} - hp;
+                    const double px_ = lv.x * nv.x, py_ = lv.y * nv.y, pz_ = lv.z * nv.z;
+                    if (!((px_ + py_ + pz_) < -1e-12 * (__builtin_fabs(px_) + __builtin_fabs(py_) + __builtin_fabs(pz_)))) break;
+                    n_shadow++; n_skipped++;
+                    EV(RTX_EV_LIGHT, 1); EV(RTX_EV_BACKFACE, 1);
+                    const double amb = m->ambient;
+                    double cr = m->a[0] * L->intensity[0] * amb, cg = m->a[1] * L->intensity[1] * amb, cb = m->a[2] * L->intensity[2] * amb;
+                    cr = cr + 0.0 + 0.0; cg = cg + 0.0 + 0.0; cb = cb + 0.0 + 0.0;      // ambient + diffuse + specular
+                    sr = sr + cr; sg = sg + cg; sb = sb + cb;
+                    light_k++;
+                }
+            }
+            if (light_k >= n_lights) lights_done = true;
+        }
+        if (shading && !lights_done) {
             // ---- is_shadowed (world.rs:195-207): next shadow ray, from over_point
+            if (light_k > 0) { Frame& f = frames[sp]; f.s[0] = sr; f.s[1] = sg; f.s[2] = sb; }   // the partial sum waits in the frame slot
             const LightRec* L = sc.lights + light_k;
             V3 over = hp + nv * 1e-10;                                            // world.rs:238-239
             V3 v = V3{L->pos[0], L->pos[1], L->pos[2]} - over;
@@ -1352,11 +1377,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     }
 #endif
     // ---- ray / event counters: one atomic per wave per counter
-    unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow);
+    unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow), t3 = wave_sum(n_skipped);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
     if (lane == 0) {
         atomicAdd(&counters[RTX_CNT_RADIANCE], (unsigned long long)t0);
         atomicAdd(&counters[RTX_CNT_SHADOW], (unsigned long long)t1);
+        if (t3) atomicAdd(&counters[RTX_CNT_SKIPPED], (unsigned long long)t3);
         if (t2 || guard_hit) {
             // never silently truncated: the count goes to the counters (synchronous renders read them) and the
             // context's sticky host word is raised (asynchronous renders: checked by the next call / rtx_ctx_poll)

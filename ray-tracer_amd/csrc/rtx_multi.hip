@@ -346,7 +346,7 @@ int rtx_render_multi(rtx_comm* const* comms, const rtx_scene* const* scenes, int
         for (int i = 0; i < n; i++) {
             stats->rays_primary += per[i].rays_primary; stats->rays_shadow += per[i].rays_shadow; stats->rays_secondary += per[i].rays_secondary;
             for (int k = 0; k < RTX_EV_COUNT; k++) stats->ev[k] += per[i].ev[k];
-            stats->overflow_pixels += per[i].overflow_pixels;
+            stats->overflow_pixels += per[i].overflow_pixels; stats->rays_shadow_skipped += per[i].rays_shadow_skipped;
             if (per[i].kernel_ms > stats->kernel_ms) stats->kernel_ms = per[i].kernel_ms;
         }
     }

@@ -90,7 +90,3 @@ def pmc_counters(workload, path=None):
             "valu_issue_frac": c["SQ_INSTS_VALU"] / (cyc * N_SIMD / 4.0),
             "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * N_SIMD),
             "resident_waves": c["SQ_WAVE_CYCLES"] * 4.0 / cyc}
-
-
-# the kernel skips shadow rays whose light is behind the surface (material.rs:67: the answer is unused); they stay counted
-SKIPS_BACKFACE_SHADOW_RAYS = False

@@ -29,7 +29,8 @@ class RtxError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_secondary", C.c_uint64),
-                ("ev", C.c_uint64 * 24), ("overflow_pixels", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("ev", C.c_uint64 * 24), ("overflow_pixels", C.c_uint64), ("kernel_ms", C.c_double),
+                ("rays_shadow_skipped", C.c_uint64)]
 
     @property
     def rays(self):
