@@ -328,6 +328,46 @@ struct ListBuilder {
     }
 };
 
+// CSG programs (rtx_device.h): the ops [begin, end) of one CSG root as self-contained records the kernel copies into LDS
+// and walks there.  Returns the program's offset in `prog` (dwords); *len_out = its length.
+int build_csg_program(const std::vector<OpRec>& ops, int begin, int end, std::vector<uint32_t>& prog, int* len_out) {
+    auto rec_size = [&](const OpRec& o) {
+        if (o.kind <= OPK_CUBE) return CSGP_SHAPE_DWORDS;
+        if (o.kind == OPK_GROUP_BEGIN || o.kind == OPK_CSG_BEGIN)
+            return o.xf == XF_GENERAL ? CSGP_BEGIN_GENERAL_DWORDS : o.xf == XF_TRANSLATE ? CSGP_BEGIN_TRANSLATE_DWORDS : CSGP_BEGIN_IDENTITY_DWORDS;
+        return CSGP_HEAD_DWORDS;
+    };
+    std::vector<int> off(end - begin + 1, 0);
+    for (int i = begin; i < end; i++) off[i - begin + 1] = off[i - begin] + rec_size(ops[i]);
+    const int base = (int)prog.size();
+    prog.resize(base + off[end - begin], 0u);
+    auto put_d = [&](uint32_t* at, const double* d, int n) { std::memcpy(at, d, (size_t)n * sizeof(double)); };
+    for (int i = begin; i < end; i++) {
+        const OpRec& o = ops[i];
+        uint32_t* r = prog.data() + base + off[i - begin];
+        const bool is_begin = o.kind == OPK_GROUP_BEGIN || o.kind == OPK_CSG_BEGIN;
+        r[0] = (uint32_t)o.kind | ((uint32_t)o.flags << 4) | ((uint32_t)o.level << 8) | ((uint32_t)o.clevel << 16);
+        if (is_begin) {
+            bool ok = true;
+            for (int k = 0; k < 6; k++) ok = ok && (std::isinf(o.bounds[k]) || std::fabs(o.bounds[k]) <= 1e100);   // NaN fails both
+            if (!ok) r[0] |= 1u << 24;
+            r[0] |= (uint32_t)o.xf << 25;
+            r[1] = (uint32_t)off[o.skip - begin];
+        }
+        r[2] = o.kind <= OPK_CUBE ? (uint32_t)i : (uint32_t)o.shape;     // shapes: their op index; CSG ops: the operator
+        r[3] = (uint32_t)rec_size(o);
+        std::memcpy(r + 4, o.cull, sizeof o.cull);
+        if (o.kind <= OPK_CUBE) { put_d(r + 8, o.inv, 12); put_d(r + 32, &o.w33, 1); }
+        else if (is_begin) {
+            put_d(r + 8, o.bounds, 6);
+            if (o.xf == XF_GENERAL) { put_d(r + 20, o.inv, 12); put_d(r + 44, &o.w33, 1); }
+            else if (o.xf == XF_TRANSLATE) { const double t[3] = {o.inv[3], o.inv[7], o.inv[11]}; put_d(r + 20, t, 3); }
+        }
+    }
+    *len_out = off[end - begin];
+    return base;
+}
+
 template <typename T>
 int upload(rtx_ctx* ctx, const std::vector<T>& v, void** out) {
     *out = nullptr;
@@ -559,21 +599,29 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         for (size_t i = 0; i < heads.size(); i++)
             fprintf(stderr, "head %zu: info=%08x skip=%d shape=%d cull=%g %g %g %g\n", i, heads[i].info, heads[i].skip,
                     heads[i].shape, heads[i].cull[0], heads[i].cull[1], heads[i].cull[2], heads[i].cull[3]);
-    std::vector<float> pairs(((heads.size() + 3) / 4 + 2) * 16, INFINITY);   // whole quads + two quads of padding
-    for (size_t i = 0; i < heads.size(); i++)
-        for (int k = 0; k < 4; k++) pairs[(i / 2) * 8 + k * 2 + (i & 1)] = heads[i].cull[k];
     ListBuilder lb(cc.ops);
     lb.build(0, (int)cc.ops.size());
     lb.finish();
+    // one program per CSG root (a CSG that is a child of the world or of a group): the record points at it
+    std::vector<uint32_t> prog;
+    int prog_max = 0;
+    for (ContRec& r : lb.conts)
+        if (r.flags & CONT_CSG) {
+            int len = 0;
+            r.list = build_csg_program(cc.ops, r.op, r.skip, prog, &len);
+            r.child_hdr[0] = (uint32_t)len;
+            prog_max = std::max(prog_max, len);
+        }
+    if (prog.empty()) prog.resize(8, 0u);
     if ((rc = upload(ctx, lb.chunks, &s->d_chunks)) || (rc = upload(ctx, lb.counts, &s->d_counts)) || (rc = upload(ctx, lb.cull, &s->d_lcull)) ||
         (rc = upload(ctx, lb.lops, &s->d_lops)) || (rc = upload(ctx, lb.conts, &s->d_conts)) ||
-        (rc = upload(ctx, pairs, &s->d_pairs)) || (rc = upload(ctx, heads, &s->d_ops)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
+        (rc = upload(ctx, prog, &s->d_pairs)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
         (rc = upload(ctx, lights, &s->d_lights))) {
         rtx_scene_destroy(s);
         return rc;
     }
-    s->dev.heads = (const OpHead*)s->d_ops; s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.cull_pairs = (const float*)s->d_pairs; s->dev.hits = (const HitRec*)s->d_shapes;
+    s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.csg_prog = (const uint32_t*)s->d_pairs; s->dev.csg_prog_max = prog_max; s->dev.hits = (const HitRec*)s->d_shapes;
     s->dev.chunks = (const ListChunk*)s->d_chunks; s->dev.chunk_counts = (const ChunkCounts*)s->d_counts; s->dev.list_cull = (const float*)s->d_lcull;
     s->dev.list_ops = (const int32_t*)s->d_lops; s->dev.cont_recs = (const ContRec*)s->d_conts;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;

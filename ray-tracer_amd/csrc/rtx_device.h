@@ -58,6 +58,17 @@ struct OpBody {
     double pad[4];
 };
 
+// ---- CSG programs: the ops of one CSG root as self-contained records (all sizes multiples of 8 dwords), in program order.
+// The kernel copies a root's program into LDS with one vector load per lane and walks it there (rtx_kernel.hip: interpret).
+//   [0] info (as OpHead.info)   [1] BEGIN ops: program offset (dwords) just past the matching END
+//   [2] shapes: their OP INDEX; CSG_BEGIN/MID/END: the operator   [3] size of this record in dwords
+//   [4..7] bounding sphere in parent space (f32 cx, cy, cz, r^2; +inf = never cull)
+//   shapes:  [8..31] inverse rows 0..2 (12 doubles), [32..33] w33
+//   BEGIN:   [8..19] local bounds (6 doubles); XF_GENERAL: [20..43] inverse rows, [44..45] w33; XF_TRANSLATE: [20..25] the
+//            translation column of the inverse; XF_IDENTITY: nothing more
+enum { CSGP_HEAD_DWORDS = 8, CSGP_SHAPE_DWORDS = 40, CSGP_BEGIN_GENERAL_DWORDS = 48, CSGP_BEGIN_TRANSLATE_DWORDS = 32,
+       CSGP_BEGIN_IDENTITY_DWORDS = 24 };
+
 // ---- child lists: the traversal outside CSG walks the graph list by list, not op by op.
 // A LIST is the ordered children of the world or of a group, cut into chunks of <= 32 children.  One sweep
 // (packed f32 bounding-sphere pre-test over the chunk's quads) tells every lane which children it may hit;
@@ -121,20 +132,19 @@ struct MaterialRec {     // 208 bytes
 struct LightRec { double pos[3]; double intensity[3]; };
 
 struct SceneDev {
-    const OpHead* heads;      // n_ops + 2 entries (padding so the 2-deep prefetch never runs off the end)
     const OpBody* bodies;
     const ListChunk* chunks;  // chunk 0 = first chunk of the world's list
     const ChunkCounts* chunk_counts;
     const float* list_cull;   // quads of bounding spheres in list order: {cxA,cxB,cyA,cyB,czA,czB,r2A,r2B} x 2 per 4 children
     const int32_t* list_ops;  // op index per child slot
     const ContRec* cont_recs;
-    const float* cull_pairs;  // per PAIR of ops (2j, 2j+1): {cxA,cxB, cyA,cyB, czA,czB, r2A,r2B}, copy of the heads' spheres
-                              //   laid out for packed-f32 math (two ops per VALU instruction)
+    const uint32_t* csg_prog; // the programs of all CSG roots (CSGP_* records below), walked from LDS by the kernel
     const HitRec* hits;       // n_ops + 1 entries, valid at shape ops
     const int32_t* path_ops;
     const MaterialRec* materials;
     const LightRec* lights;
     int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = deepest list level + 1
+    int32_t csg_prog_max;                          // longest CSG root program in dwords (LDS area of the interpreter)
     int32_t n_org_slots, n_dir_slots;              // LDS ray stack: origin / direction slots needed (rtx_kernel.hip)
     int32_t has_csg, has_transparency;
     int32_t csg_entries, has_branching;  // has_branching: some material is reflective AND transparent (two children per hit)  // largest number of list entries a CSG root can produce (LDS list area per lane)

@@ -342,9 +342,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     const int tx = tile % rp.tiles_x, bl = tile / rp.tiles_x;
     const int band = rp.band_first + bl * rp.band_stride;
 
-    const AS4 OpHead* heads = (const AS4 OpHead*)(uintptr_t)sc.heads;
     const AS4 OpBody* bodies = (const AS4 OpBody*)(uintptr_t)sc.bodies;
-    const int n_ops = sc.n_ops;
     const int n_lights = sc.n_lights;
 
     // ---- per-lane counters
@@ -435,7 +433,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     // split mailboxes (after the CSG lists): colour [3][64] indexed by the SENDER's lane + a posted flag per lane.
     // A lane posts at most once (then it retires), so one box per lane is enough for all levels.
     // mb_state: 0 free, 1 a task is running on this lane, 2 its colour is posted and not yet taken
-    volatile double* const mb_ = lds_after + (sc.csg_entries * 64 * 12 + 7) / 8;
+    // the program of the CSG root being walked (after the lists; 16-byte aligned), then the split mailboxes
+    uint32_t* const prog_lds = (uint32_t*)(lds_after + ((sc.csg_entries * 64 * 12 + 15) / 16) * 2);
+    volatile double* const mb_ = (volatile double*)(prog_lds + sc.csg_prog_max);
     volatile int* const mb_state = (volatile int*)(mb_ + 3 * 64);
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // running state instead of a sorted hit list; shapes are identified by op index
         double best_t = 0.0; int best_op = -1; bool best_inside = false;
         double c1t = -INF, c2t = -INF; int c1s = -1, c2s = -1;     // refractive containers
-        int resume_at = n_ops;            // op interpreter (CSG roots): first op the lane takes part in again
+        int resume_at = 0x7fffffff;       // CSG interpreter: first program offset the lane takes part in again
         int alive = (mode != MODE_DONE) ? 0 : -1;   // deepest list level the lane takes part in
         bool decided = false;             // shadow ray already answered (world.rs:203-206)
         int cnt = 0;                      // CSG list length
@@ -535,83 +535,68 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             else { lo = po; ld = pd; }
         };
 
-        // ---- the op interpreter: walks the ops [cur, end) of ONE CSG root in program order (hit lists need
-        // the reference's order); everything outside CSG goes through the child lists below
-        auto interpret = [&](int cur, const int end) {
-        const int root_op = cur;
-        while (cur < end) {
+        // ---- the CSG interpreter: walks the PROGRAM of ONE CSG root in program order (hit lists need the reference's order;
+        // everything outside CSG goes through the child lists below).  The program (rtx_device.h: CSG program records —
+        // heads, container transforms and bounds, the shapes' inverses) is copied into LDS by the whole wave with one
+        // vector load per lane, and every record is then read from LDS: walking a root costs ONE trip to memory instead
+        // of two or three dependent scalar round trips per op.  `cur` / resume_at are dword offsets into the program.
+        auto interpret = [&](const int poff, const int plen) {
+        {
+            typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+            const U4* src = (const U4*)(sc.csg_prog + poff);
+            U4* dst = (U4*)prog_lds;
+            for (int i = lane; i < (plen >> 2); i += 64) dst[i] = src[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        int cur = 0;
+        while (cur < plen) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             cached_level = __builtin_amdgcn_readfirstlane(cached_level);
             const bool active = cur >= resume_at;
             if (!__any(active)) {
-                cur = __builtin_amdgcn_readfirstlane(wave_min(resume_at));   // keep the op index scalar
+                cur = __builtin_amdgcn_readfirstlane(wave_min(resume_at));   // keep the offset scalar
                 continue;
             }
-            const Head h = load_head(heads + cur);
-            const int kind = OPH_KIND(H_INFO(h));
-            const int level = OPH_LEVEL(H_INFO(h));
-            const int flags = OPH_FLAGS(H_INFO(h));
-            int next = cur + 1;
+            const uint32_t* rec = prog_lds + cur;
+            const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[0]);
+            const int kind = OPH_KIND(info);
+            const int level = OPH_LEVEL(info);
+            const int flags = OPH_FLAGS(info);
+            const int aux = __builtin_amdgcn_readfirstlane((int)rec[2]);
+            int next = cur + __builtin_amdgcn_readfirstlane((int)rec[3]);
+            const float cu0 = as_f32(rec[4]), cu1 = as_f32(rec[5]), cu2 = as_f32(rec[6]), cu3 = as_f32(rec[7]);
+            // conservative bounding-sphere pre-test (see cull_miss)
+            auto sphere_miss = [&]() {
+                const float ocx = cu0 - fox, ocy = cu1 - foy, ocz = cu2 - foz;
+                const float od = __builtin_fmaf(ocz, fdz, __builtin_fmaf(ocy, fdy, ocx * fdx));
+                const float oo = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+                const float lhs = __builtin_fmaf(oo, fdd, -(od * od));
+                const float rhs = __builtin_fmaf(CULL_KAPPA, oo, cu3) * fdd;
+                return lhs > rhs;                                             // false on NaN
+            };
 
             if (kind <= OPK_CUBE) {
-                // ================= a RUN of consecutive shapes of one level (host-marked, <= 64 ops)
+                // ================= one shape: ObjectStore::intersect (object_store.rs:243-260) for every lane still in
                 TM(tm_other);
-                const int R = H_RUN(h);
                 sync_level(level);
-                uint64_t cand = 0;
-                {
-                    // ---- phase 1: conservative bounding-sphere pre-test of every op of the run for every
-                    // lane (cull_miss2: no counterpart in the reference, cannot change a result).  Tight
-                    // uniform loop over PAIRS of ops (2j, 2j+1): one scalar load of the pair's spheres and
-                    // ~15 packed-f32 VALU instructions per pair, no per-lane state but the candidate bits.
-                    // Scalar loads return out of order (only lgkmcnt(0) can be waited for), so the loop is a
-                    // ping-pong over QUADS of ops: one s_load_dwordx16 (two pairs) is in flight while the
-                    // previous quad is evaluated.  The pointers are made opaque so the rotation is not folded away.
-                    const AS4 F16* cq = (const AS4 F16*)(uintptr_t)sc.cull_pairs;
-                    const int q0 = cur >> 2, q1 = (cur + R - 1) >> 2;
-                    uint64_t acc = 0;
-                    F16 qa = cq[q0];
-                    for (int q = q0; q <= q1; q += 2) {
-                        const AS4 F16* pb = cq + q + 1;
-                        asm volatile("" : "+s"(pb));
-                        const F16 qb = *pb;                                      // (array is padded by two quads)
-                        acc |= (uint64_t)cull_hit4(qa, fox, foy, foz, fdx, fdy, fdz, fdd) << (4 * (q - q0));
-                        const AS4 F16* pa = cq + q + 2;
-                        asm volatile("" : "+s"(pa));
-                        qa = *pa;
-                        // (branch-free so both loads stay ahead of the math: past the end the bits are masked off)
-                        const unsigned keep = (q + 1 <= q1) ? 0xfu : 0u;
-                        acc |= (uint64_t)(cull_hit4(qb, fox, foy, foz, fdx, fdy, fdz, fdd) & keep) << ((4 * (q + 1 - q0)) & 63);
-                    }
-                    cand = (acc >> (cur & 3)) & ((1ull << R) - 1ull);            // (cur & 3) + R <= 64
-                    if (COUNT && active) {
-                        EV(RTX_EV_XFORM, R); EV(RTX_EV_CULL, R);
-                        for (int i = 0; i < R; i++) {
-                            const int kk = OPH_KIND(heads[cur + i].info);
-                            if (kk == OPK_SPHERE) EV(RTX_EV_SPHERE, 1);
-                            else if (kk == OPK_PLANE) EV(RTX_EV_PLANE, 1);
-                            else EV(RTX_EV_CUBE, 1);
-                        }
-                    }
+                const int idx = aux;                                          // the shape's op index (its identity)
+                if (active) {
+                    EV(RTX_EV_XFORM, 1); EV(RTX_EV_CULL, 1);
+                    if (kind == OPK_SPHERE) EV(RTX_EV_SPHERE, 1); else if (kind == OPK_PLANE) EV(RTX_EV_PLANE, 1); else EV(RTX_EV_CUBE, 1);
                 }
-                if (!active) cand = 0;
-                EV(RTX_EV_OP_SLOTS, R);
+                EV(RTX_EV_OP_SLOTS, 1);
+                const bool cand = active && !sphere_miss();
                 TMT(tm_ffwd);
-                // ---- phase 2: every lane walks ITS OWN surviving ops in program order (lowest bit first,
-                // so ties resolve as in the reference's stable sort); node records come through per-lane
-                // vector loads.  ObjectStore::intersect (object_store.rs:243-260) for one shape per lane.
-                while (__any(cand != 0)) {
-                    if (cand != 0) {
-                        const int i = __builtin_ctzll(cand);
-                        cand &= cand - 1;
-                        const int idx = cur + i;
-                        const OpBody* gb = sc.bodies + idx;
-                        const int k1 = gb->kind;
-                        V3 lo = xf_point(gb->inv, gb->w33, gb->div != 0, po);
-                        V3 ld = xf_vector(gb->inv, pd);
+                if (__any(cand)) {
+                    const double* inv = (const double*)(rec + 8);
+                    V3 lo = xf_point(inv, inv[12], (flags & OPF_DIV) != 0, po);
+                    V3 ld = xf_vector(inv, pd);
+                    if (cand) {
                         EV(RTX_EV_X_XFORM, 1);
                         int k = 0; double t0 = 0.0, t1 = 0.0;
-                        if (k1 == OPK_SPHERE) {                   // sphere.rs:16-32
+                        if (kind == OPK_SPHERE) {                 // sphere.rs:16-32
                             EV(RTX_EV_X_SPHERE, 1);
                             double a = dot3(ld, ld);
                             double b = 2.0 * dot3(ld, lo);
@@ -623,68 +608,68 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                                 t1 = (-b + sq) / (2.0 * a);
                                 k = 2;
                             }
-                        } else if (k1 == OPK_PLANE) {             // plane.rs:16-23
+                        } else if (kind == OPK_PLANE) {           // plane.rs:16-23
                             if (!(__builtin_fabs(ld.y) < 1e-12)) { t0 = -lo.y / ld.y; k = 1; }
                         } else {                                  // cube.rs:18-31
                             EV(RTX_EV_X_BOX, 1);
                             if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
                         }
-                        // (every op under a CSG root carries OPF_LIST: hits go to the per-lane list, in program order)
+                        // (every op under a CSG root goes to the per-lane list, in program order)
                         if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
                         if (k >= 1) { lt(cnt) = t0; ls(cnt) = (uint32_t)idx; cnt++; }
                         if (k == 2) { lt(cnt) = t1; ls(cnt) = (uint32_t)idx; cnt++; }
                     }
                 }
-                next = cur + R;
                 TMT(tm_body);
             } else if (kind == OPK_GROUP_BEGIN || kind == OPK_CSG_BEGIN) {
                 sync_level(level);
-                if (active && cur != root_op) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_BOUNDS, 1); }   // (the root was counted with its list)
+                const int skip = __builtin_amdgcn_readfirstlane((int)rec[1]);
+                if (active && cur != 0) { EV(RTX_EV_XFORM, 1); EV(RTX_EV_BOUNDS, 1); }   // (the root was counted with its list)
                 EV(RTX_EV_OP_SLOTS, 1);
-                // conservative pre-test of the container's bounding sphere (see cull_miss)
                 bool test = active;
-                if (H_CULL(h, 3) < __builtin_inff()) {
-                    const bool miss = cull_miss(h, fox, foy, foz, fdx, fdy, fdz, fdd);
+                if (cu3 < __builtin_inff()) {
+                    const bool miss = sphere_miss();
                     if (active) EV(RTX_EV_CULL, 1);
                     test = active && !miss;
-                    if (active && miss) resume_at = H_SKIP(h);
+                    if (active && miss) resume_at = skip;
                 }
                 if (!__any(test)) {
-                    next = H_SKIP(h);
+                    next = skip;
                 } else {
                     // ---- Groups::local_intersect (group.rs:64-75) / CSGs::local_intersect (csg.rs:73-78)
-                    const AS4 OpBody* op = bodies + cur;
-                    const int xf = OPH_XF(H_INFO(h));
+                    const double* bnd = (const double*)(rec + 8);             // local bounds, then the transform data
+                    const double* xd = bnd + 6;
+                    const int xf = OPH_XF(info);
                     V3 lo, ld;
-                    into_container(op->inv, op->w33, (flags & OPF_DIV) != 0, xf, lo, ld);
+                    if (xf == XF_GENERAL) { lo = xf_point(xd, xd[12], (flags & OPF_DIV) != 0, po); ld = xf_vector(xd, pd); }
+                    else if (xf == XF_TRANSLATE) { lo = V3{po.x + xd[0], po.y + xd[1], po.z + xd[2]}; ld = pd; }
+                    else { lo = po; ld = pd; }
                     if (test) EV(RTX_EV_X_XFORM, 1);
                     // decision by the interval filter; the exact slab test (six divisions) only where a lane is undecided
-                    const int fdec = OPH_NOFILTER(H_INFO(h)) ? -1
-                        : slab_filter(lo, ld, op->bounds[0], op->bounds[1], op->bounds[2], op->bounds[3], op->bounds[4], op->bounds[5]);
+                    const int fdec = OPH_NOFILTER(info) ? -1 : slab_filter(lo, ld, bnd[0], bnd[1], bnd[2], bnd[3], bnd[4], bnd[5]);
                     bool pass = test && fdec == 1;
                     const bool undecided = test && fdec < 0;
                     if (__any(undecided)) {
                         if (undecided) EV(RTX_EV_X_BOX, 1);
                         double tmin, tmax;
-                        const bool ex = slabs(lo, ld, op->bounds[0], op->bounds[1], op->bounds[2],
-                                              op->bounds[3], op->bounds[4], op->bounds[5], tmin, tmax);
+                        const bool ex = slabs(lo, ld, bnd[0], bnd[1], bnd[2], bnd[3], bnd[4], bnd[5], tmin, tmax);
                         pass = pass || (undecided && ex);
                     }
-                    if (test && !pass) resume_at = H_SKIP(h);
+                    if (test && !pass) resume_at = skip;
                     if (!__any(pass)) {
-                        next = H_SKIP(h);
+                        next = skip;
                     } else {
                         // the children (level + 1) walk in this node's space
                         po = lo; pd = ld;
                         enter_level(level, xf, pass);
                         if (pass) {
-                            const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
+                            const int sh = OPH_CLEVEL(info) * 8;
                             starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                         }
                     }
                 }
             } else if (active) {
-                const int sh = OPH_CLEVEL(H_INFO(h)) * 8;
+                const int sh = OPH_CLEVEL(info) * 8;
                 if (kind == OPK_CSG_MID) {
                     mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                 } else {
@@ -703,7 +688,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     }
                     if (kind == OPK_CSG_END) {
                         // filter_intersections (csg.rs:94-121)
-                        const int cop = H_SHAPE(h);
+                        const int cop = aux;
                         bool inl = false, inr = false;
                         int out = s0;
                         for (int i = s0; i < cnt; i++) {
@@ -748,7 +733,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                                 }
                             }
                             cnt = 0;
-                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = n_ops; decided = true; }
+                            if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = 0x7fffffff; decided = true; }
                         }
                     }
                 }
@@ -892,10 +877,11 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     const int cflags = cr->flags;
                     if (CSG && (cflags & CONT_CSG)) {
                         if constexpr (CSG) {
-                            const int cop = cr->op, cend = cr->skip;
-                            resume_at = act ? cop : n_ops;
+                            // (a CSG root's record: `list` = offset of its program in csg_prog, child_hdr[0] = its length, dwords)
+                            const int poff = cr->list, plen = (int)cr->child_hdr[0];
+                            resume_at = act ? 0 : 0x7fffffff;
                             cnt = 0; starts = 0; mids = 0;
-                            interpret(cop, cend);
+                            interpret(poff, plen);
                         }
                         continue;
                     }
@@ -1410,7 +1396,8 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
     if (blocks <= 0) return hipSuccess;
     const bool split = !rp->probe && rp->use_lists && rp->split_cap > 0 && rp->split_launch;
     if (split) blocks = rp->split_cap << RTX_SPLIT_BITS;
-    size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 7) & ~(size_t)7);
+    size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 15) & ~(size_t)15) +
+                 (size_t)sc->csg_prog_max * sizeof(uint32_t);
     if (split) lds += 64 * (3 * sizeof(double) + 2 * sizeof(int));
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
