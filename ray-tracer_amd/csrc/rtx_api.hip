@@ -295,6 +295,7 @@ struct ListBuilder {
                     ch.cont_mask |= 1u << k; cn.containers++;
                     ContRec r; std::memset(&r, 0, sizeof r);
                     std::memcpy(r.inv, o.inv, sizeof r.inv); r.w33 = o.w33; std::memcpy(r.bounds, o.bounds, sizeof r.bounds);
+                    r.t[0] = o.inv[3]; r.t[1] = o.inv[7]; r.t[2] = o.inv[11];
                     std::memcpy(r.cull, o.cull, sizeof r.cull);
                     r.op = op; r.skip = o.skip; r.list = -1;
                     bool ok = true;
@@ -572,7 +573,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         }
         h.skip = o.skip; h.shape = o.shape;
         std::memcpy(h.cull, o.cull, sizeof h.cull);
-        std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33; std::memcpy(b.bounds, o.bounds, sizeof b.bounds);
+        std::memcpy(b.inv, o.inv, sizeof b.inv); b.w33 = o.w33;
         b.div = (o.flags & OPF_DIV) ? 1 : 0; b.kind = o.kind;
         if (o.kind <= OPK_CUBE) {
             const ShapeRec& sr = cc.shapes[o.shape];

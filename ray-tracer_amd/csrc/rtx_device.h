@@ -49,13 +49,12 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
 enum { XF_GENERAL = 0,     // any affine map: origin and direction change
        XF_TRANSLATE = 1,   // linear part exactly the identity, w33 == 1: the direction is unchanged, origin = p + t
        XF_IDENTITY = 2 };  // ... and t == 0: the ray is unchanged (CSG operands without a transform of their own)   // container bounds unsuitable for the interval filter (NaN or |finite| > 1e100)
-struct OpBody {
+struct __attribute__((aligned(128))) OpBody {   // 128 bytes = one L2 line per shape for the per-lane gathers
     double inv[12];    // rows 0..2 of inverse(transform): inv[r*4+c]
     double w33;        // inverse(3,3)
-    double bounds[6];  // containers: local bounds {min xyz, max xyz}
     int32_t div;       // w33 != 1.0 (copy of OPF_DIV, so shading needs no head load)
     int32_t kind;      // copy of the head's kind, so the per-lane exact tests read one record
-    double pad[4];
+    double pad[2];
 };
 
 // ---- CSG programs: the ops of one CSG root as self-contained records (all sizes multiples of 8 dwords), in program order.
@@ -84,17 +83,21 @@ struct ListChunk {           // 32 bytes = one s_load_dwordx8
     int32_t cont_base;       // cont_recs[cont_base + r] = r-th container child of this chunk
 };
 #define LIST_KINDS_SHIFT 0
-struct __attribute__((aligned(32))) ContRec {   // 224 bytes: everything a visit of a container child needs, one scalar round trip
+struct __attribute__((aligned(128))) ContRec {   // 256 bytes; the kernel reads the first half with one batch of scalar loads
+    // ---- first half (128 bytes): all a visit needs unless the transform is XF_GENERAL
+    float cull[4];           // bounding sphere in parent space (same as the sweep's)
+    int32_t list;            // groups: first chunk of the child list; CSG roots: offset of the program in csg_prog (dwords)
+    int32_t flags;           // CONT_* | XF_* << CONT_XF_SHIFT
+    double t[3];             // translation column of the inverse (XF_TRANSLATE: origin = p + t)
+    double bounds[6];        // local bounds
+    uint32_t child_hdr[8];   // groups: copy of the ListChunk `list` points at (the descent needs no second round trip);
+                             //   CSG roots: [0] = length of the program in dwords
+    // ---- second half (128 bytes): XF_GENERAL only
     double inv[12];          // rows 0..2 of inverse(transform)
     double w33;
-    double bounds[6];
-    float cull[4];           // bounding sphere in parent space (same as the sweep's)
-    int32_t op;              // the container's BEGIN op
-    int32_t skip;            // op index past the container (range of a CSG root for the op interpreter)
-    int32_t list;            // first chunk of its child list (groups), -1 for a CSG root
-    int32_t flags;           // CONT_*
-    uint32_t pad0[2];
-    uint32_t child_hdr[8];   // groups: copy of the ListChunk `list` points at (the descent needs no second round trip)
+    int32_t op;              // the container's BEGIN op      (host side)
+    int32_t skip;            // op index past the container    (host side)
+    uint32_t pad1[4];
 };
 enum { CONT_DIV = 1, CONT_NOFILTER = 2, CONT_CSG = 4, CONT_XF_SHIFT = 4 };
 #define CONT_XF(f) (((f) >> CONT_XF_SHIFT) & 3)

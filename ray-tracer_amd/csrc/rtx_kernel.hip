@@ -361,12 +361,26 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 #endif
     // RTX_TIMING == 2: the traversal is one bucket ("other") and the cull/exact slots time the shadow-ray
     // set-up and the children decision instead; "shade" is then the unwind + loop turn-around
-#if defined(RTX_TIMING) && RTX_TIMING == 2
+// RTX_TIMING == 3: the CSG interpreter in detail — cull = its shape ops, exact = its BEGIN ops, shade = its MID / END list work,
+// prep = the program copy into LDS, other = the rest of the traversal, light = all shading
+#if defined(RTX_TIMING) && RTX_TIMING == 3
+#define TMI(acc) TM(acc)
+#else
+#define TMI(acc) do { } while (0)
+#endif
+#if defined(RTX_TIMING) && RTX_TIMING == 3
+#define TMT(acc) do { } while (0)
+#define TMS(acc) TM(tm_light)
+#define TML(acc) TM(tm_light)
+#elif defined(RTX_TIMING) && RTX_TIMING == 2
 #define TMT(acc) TM(tm_other)
 #define TMS(acc) TM(acc)
 #else
 #define TMT(acc) TM(acc)
 #define TMS(acc) do { } while (0)
+#endif
+#ifndef TML
+#define TML(acc) TM(acc)
 #endif
 
     int mode;
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                                           // construction — helpers never wait for their owners — but a hung wave hangs the GPU)
     while (__any(mode != MODE_DONE || (SPLIT && waiting))) {
         if (SPLIT && ++guard > rp.split_guard) { guard_hit = true; break; }
-        TM(tm_shade);
+        TML(tm_shade);
         // ================================================================= TRACE
         // World::intersect (world.rs:111-118) for every lane's current ray.
 #ifdef RTX_WAVE_TRACE
@@ -525,15 +539,11 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             }
             cached_level = level + 1;
         };
-        // ray into a container's space (object_store.rs:244-246, rays.rs:21-23).  A translation's inverse has the identity as
-        // its linear part: the direction is unchanged and the origin is p + t (the products by 1 and the sums with products
-        // by 0 of the general formula change nothing but the sign of a zero, which no later operation can observe: zeros of
-        // ray components are only ever added, multiplied and compared, never divided by); the identity changes nothing.
-        auto into_container = [&](const auto* inv, double w33, bool div, int xf, V3& lo, V3& ld) {
-            if (xf == XF_GENERAL) { lo = xf_point(inv, w33, div, po); ld = xf_vector(inv, pd); }
-            else if (xf == XF_TRANSLATE) { lo = V3{po.x + inv[3], po.y + inv[7], po.z + inv[11]}; ld = pd; }
-            else { lo = po; ld = pd; }
-        };
+        // Ray into a container's space (object_store.rs:244-246, rays.rs:21-23), by transform class.  A translation's inverse has
+        // the identity as its linear part: the direction is unchanged and the origin is p + t (the products by 1 and the sums
+        // with products by 0 of the general formula change nothing but the sign of a zero, which no later operation can
+        // observe: zeros of ray components are only ever added, multiplied and compared, never divided by); the identity
+        // changes nothing.
 
         // ---- the CSG interpreter: walks the PROGRAM of ONE CSG root in program order (hit lists need the reference's order;
         // everything outside CSG goes through the child lists below).  The program (rtx_device.h: CSG program records —
@@ -541,6 +551,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // vector load per lane, and every record is then read from LDS: walking a root costs ONE trip to memory instead
         // of two or three dependent scalar round trips per op.  `cur` / resume_at are dword offsets into the program.
         auto interpret = [&](const int poff, const int plen) {
+        TMI(tm_other);
         {
             typedef uint32_t U4 __attribute__((ext_vector_type(4)));
             const U4* src = (const U4*)(sc.csg_prog + poff);
@@ -550,6 +561,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        TMI(tm_prep);
         int cur = 0;
         while (cur < plen) {
             cur = __builtin_amdgcn_readfirstlane(cur);
@@ -621,6 +633,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     }
                 }
                 TMT(tm_body);
+                TMI(tm_ffwd);
             } else if (kind == OPK_GROUP_BEGIN || kind == OPK_CSG_BEGIN) {
                 sync_level(level);
                 const int skip = __builtin_amdgcn_readfirstlane((int)rec[1]);
@@ -668,6 +681,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         }
                     }
                 }
+                TMI(tm_body);
             } else if (active) {
                 const int sh = OPH_CLEVEL(info) * 8;
                 if (kind == OPK_CSG_MID) {
@@ -738,6 +752,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     }
                 }
             }
+            TMI(tm_shade);
             cur = next;
         }
         };
@@ -873,12 +888,22 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 if (U != 0) {
                     const int c = __builtin_ctz(U);
                     U &= U - 1;
-                    const AS4 ContRec* cr = conts + (int)hdr[7] + __builtin_popcount(hdr[4] & ((1u << c) - 1u));
-                    const int cflags = cr->flags;
+                    // one container child: the first half of its record (ContRec: everything but a general transform's matrix)
+                    // arrives with ONE batch of scalar loads — field-by-field access made the compiler wait five times in a row
+                    typedef uint32_t U16 __attribute__((ext_vector_type(16)));
+                    const AS4 U16* crp = (const AS4 U16*)(conts + (int)hdr[7] + __builtin_popcount(hdr[4] & ((1u << c) - 1u)));
+                    U16 ra = crp[0], rb = crp[1];
+                    {   // (both loads must be in flight before the first use: tie one element of each to an opaque point)
+                        uint32_t e0 = ra[5], e1 = rb[8];
+                        asm volatile("" : "+s"(e0), "+s"(e1));
+                        ra[5] = e0; rb[8] = e1;
+                    }
+                    auto f64_of = [](uint32_t lo_, uint32_t hi_) { return __builtin_bit_cast(double, (uint64_t)lo_ | ((uint64_t)hi_ << 32)); };
+                    const int cflags = (int)ra[5];
                     if (CSG && (cflags & CONT_CSG)) {
                         if constexpr (CSG) {
                             // (a CSG root's record: `list` = offset of its program in csg_prog, child_hdr[0] = its length, dwords)
-                            const int poff = cr->list, plen = (int)cr->child_hdr[0];
+                            const int poff = (int)ra[4], plen = (int)rb[8];
                             resume_at = act ? 0 : 0x7fffffff;
                             cnt = 0; starts = 0; mids = 0;
                             interpret(poff, plen);
@@ -891,25 +916,29 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     bool test = act;
                     {
                         Head ch = {};
-                        ch[4] = __builtin_bit_cast(uint32_t, cr->cull[0]); ch[5] = __builtin_bit_cast(uint32_t, cr->cull[1]);
-                        ch[6] = __builtin_bit_cast(uint32_t, cr->cull[2]); ch[7] = __builtin_bit_cast(uint32_t, cr->cull[3]);
+                        ch[4] = ra[0]; ch[5] = ra[1]; ch[6] = ra[2]; ch[7] = ra[3];
                         if (cull_miss(ch, fox, foy, foz, fdx, fdy, fdz, fdd)) test = false;
                     }
                     if (__any(test)) {
                         const int xf = CONT_XF(cflags);
                         V3 lo, ld;
-                        into_container(cr->inv, cr->w33, (cflags & CONT_DIV) != 0, xf, lo, ld);
+                        if (xf == XF_GENERAL) {
+                            const AS4 double* gi = (const AS4 double*)(crp + 2);      // the second half: inverse rows + w33
+                            lo = xf_point(gi, gi[12], (cflags & CONT_DIV) != 0, po); ld = xf_vector(gi, pd);
+                        } else if (xf == XF_TRANSLATE) {
+                            lo = V3{po.x + f64_of(ra[6], ra[7]), po.y + f64_of(ra[8], ra[9]), po.z + f64_of(ra[10], ra[11])}; ld = pd;
+                        } else { lo = po; ld = pd; }
                         if (test) EV(RTX_EV_X_XFORM, 1);
+                        const double b0 = f64_of(ra[12], ra[13]), b1 = f64_of(ra[14], ra[15]), b2 = f64_of(rb[0], rb[1]),
+                                     b3 = f64_of(rb[2], rb[3]), b4 = f64_of(rb[4], rb[5]), b5 = f64_of(rb[6], rb[7]);
                         // decision by the interval filter; the exact slab test (six divisions) only where a lane is undecided
-                        const int fdec = (cflags & CONT_NOFILTER) ? -1
-                            : slab_filter(lo, ld, cr->bounds[0], cr->bounds[1], cr->bounds[2], cr->bounds[3], cr->bounds[4], cr->bounds[5]);
+                        const int fdec = (cflags & CONT_NOFILTER) ? -1 : slab_filter(lo, ld, b0, b1, b2, b3, b4, b5);
                         bool pass = test && fdec == 1;
                         const bool undecided = test && fdec < 0;
                         if (__any(undecided)) {
                             if (undecided) EV(RTX_EV_X_BOX, 1);
                             double tmin, tmax;
-                            const bool ex = slabs(lo, ld, cr->bounds[0], cr->bounds[1], cr->bounds[2],
-                                                  cr->bounds[3], cr->bounds[4], cr->bounds[5], tmin, tmax);
+                            const bool ex = slabs(lo, ld, b0, b1, b2, b3, b4, b5, tmin, tmax);
                             pass = pass || (undecided && ex);
                         }
                         if (__any(pass)) {
@@ -920,8 +949,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             // lane-indexed uniform arrays: what the walk needs of this chunk when it comes back (no header reload)
                             if (lane == level) { stk_chunk = chunk; stk_U = (int)U; stk_cm = (int)hdr[4]; stk_next = (int)hdr[5]; stk_cb = (int)hdr[7]; }
                             level = level + 1;
-                            chunk = cr->list;
-                            hdr = *(const AS4 Head*)cr->child_hdr;     // the first chunk of the child list travels with the record
+                            chunk = (int)ra[4];
+                            // the first chunk of the child list travels with the record
+                            hdr = Head{rb[8], rb[9], rb[10], rb[11], rb[12], rb[13], rb[14], rb[15]};
                             have_hdr = true;
                             fresh = true;
                         }
@@ -1005,7 +1035,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 light_k = 0;
                 shading = true;
             }
-            TM(tm_prep);
+            TML(tm_prep);
         } else if (mode == MODE_SHADOW) {
             // ---- lighting for light_k (material.rs:54-81) with the shadow answer of this trace
             const bool in_shadow = best_op >= 0 && best_t < shadow_dist;
