@@ -610,7 +610,8 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         if (r.flags & CONT_CSG) {
             int len = 0;
             r.list = build_csg_program(cc.ops, r.op, r.skip, prog, &len);
-            r.child_hdr[0] = (uint32_t)len;
+            std::memset(r.t, 0, sizeof r.t);
+            std::memcpy(r.t, &len, sizeof len);          // (a CSG root's `t` is unused by the list walk: it carries the length)
             prog_max = std::max(prog_max, len);
         }
     if (prog.empty()) prog.resize(8, 0u);

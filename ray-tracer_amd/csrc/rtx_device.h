@@ -88,10 +88,10 @@ struct __attribute__((aligned(128))) ContRec {   // 256 bytes; the kernel reads 
     float cull[4];           // bounding sphere in parent space (same as the sweep's)
     int32_t list;            // groups: first chunk of the child list; CSG roots: offset of the program in csg_prog (dwords)
     int32_t flags;           // CONT_* | XF_* << CONT_XF_SHIFT
-    double t[3];             // translation column of the inverse (XF_TRANSLATE: origin = p + t)
+    double t[3];             // translation column of the inverse (XF_TRANSLATE: origin = p + t); CSG roots: the first
+                             //   32-bit word = length of the program in dwords
     double bounds[6];        // local bounds
     uint32_t child_hdr[8];   // groups: copy of the ListChunk `list` points at (the descent needs no second round trip);
-                             //   CSG roots: [0] = length of the program in dwords
     // ---- second half (128 bytes): XF_GENERAL only
     double inv[12];          // rows 0..2 of inverse(transform)
     double w33;

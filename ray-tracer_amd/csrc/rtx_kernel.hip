@@ -203,9 +203,10 @@ DI float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 // the node lies inside the sphere (centre c, radius^2 r2) of its parent's space.  A line whose
 // distance to c exceeds the radius by the margins folded into r2 and CULL_KAPPA has no intersection
 // with the node at ANY t, so the reference's exact test would return an empty list as well.
-DI bool cull_miss(Head h, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd) {
+// od_min: -inf = test against the whole line, 0 = against the half-line t >= 0 (see cull_hit2)
+DI bool cull_miss(Head h, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd, float od_min) {
     const float ocx = H_CULL(h, 0) - fox, ocy = H_CULL(h, 1) - foy, ocz = H_CULL(h, 2) - foz;
-    const float od = __builtin_fmaf(ocz, fdz, __builtin_fmaf(ocy, fdy, ocx * fdx));
+    const float od = __builtin_fmaxf(__builtin_fmaf(ocz, fdz, __builtin_fmaf(ocy, fdy, ocx * fdx)), od_min);
     const float oo = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
     const float lhs = __builtin_fmaf(oo, fdd, -(od * od));            // dist^2 * |d|^2
     const float rhs = __builtin_fmaf(CULL_KAPPA, oo, H_CULL(h, 3)) * fdd;
@@ -226,20 +227,27 @@ DI V3 to_object(const SceneDev& sc, const HitRec& hr, int hop, V3 p) {
 // cyA,cyB, czA,czB, r2A,r2B}.  Returns bit 0 / bit 1 = op A / op B may be hit (NaN counts as "may be hit").
 typedef float F2 __attribute__((ext_vector_type(2)));
 typedef float F8 __attribute__((ext_vector_type(8)));
-DI unsigned cull_hit2(F8 p, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd) {
+// `od_min` (0 or -inf, wave-uniform): with 0 the test is against the HALF-line t >= 0 instead of the whole line — where the
+// centre lies behind the origin plane (oc . d < 0) the closest point of the half-line is the origin itself, so the projection
+// is clamped at 0 and a child whose whole bounding sphere lies behind the ray origin is dropped: all its intersections have
+// t < 0.  For a sphere or a cube (0 or 2 entries) such entries change nothing: not the closest hit, not a shadow answer, and
+// a shape with BOTH entries negative is no refractive container (world.rs:258-296 keeps the shapes with exactly one).  A
+// CSG's filtered list can keep an odd number of a shape's entries, so containers are only dropped this way in scenes
+// without transparency (n1 / n2 are never consumed there); the caller decides.  One packed max per pair of children.
+DI unsigned cull_hit2(F8 p, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd, float od_min) {
     const F2 ocx = F2{p[0], p[1]} - F2{fox, fox}, ocy = F2{p[2], p[3]} - F2{foy, foy}, ocz = F2{p[4], p[5]} - F2{foz, foz};
     const F2 dx = {fdx, fdx}, dy = {fdy, fdy}, dz = {fdz, fdz}, dd = {fdd, fdd};
-    const F2 od = __builtin_elementwise_fma(ocz, dz, __builtin_elementwise_fma(ocy, dy, ocx * dx));
+    const F2 od = __builtin_elementwise_max(__builtin_elementwise_fma(ocz, dz, __builtin_elementwise_fma(ocy, dy, ocx * dx)), F2{od_min, od_min});
     const F2 oo = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx));
     const F2 lhs = __builtin_elementwise_fma(oo, dd, -(od * od));              // dist^2 * |d|^2
     const F2 rhs = __builtin_elementwise_fma(F2{CULL_KAPPA, CULL_KAPPA}, oo, F2{p[6], p[7]}) * dd;
     return (lhs[0] > rhs[0] ? 0u : 1u) | (lhs[1] > rhs[1] ? 0u : 2u);
 }
 typedef float F16 __attribute__((ext_vector_type(16)));
-DI unsigned cull_hit4(F16 p, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd) {
+DI unsigned cull_hit4(F16 p, float fox, float foy, float foz, float fdx, float fdy, float fdz, float fdd, float behind) {
     const F8 lo = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
     const F8 hi = {p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]};
-    return cull_hit2(lo, fox, foy, foz, fdx, fdy, fdz, fdd) | (cull_hit2(hi, fox, foy, foz, fdx, fdy, fdz, fdd) << 2);
+    return cull_hit2(lo, fox, foy, foz, fdx, fdy, fdz, fdd, behind) | (cull_hit2(hi, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << 2);
 }
 
 enum { MODE_DONE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
@@ -803,6 +811,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         // lgkmcnt(0) can be waited for), so the loop is a ping-pong over QUADS of children: two
                         // s_load_dwordx16 are in flight per wait.  The pointers are opaque so the rotation stays.
                         unsigned cand = 0;
+                        // (children wholly behind the ray origin are dropped too — see cull_hit2 — unless the chunk has containers
+                        // and the scene has transparent materials)
+                        // (... and, in the reference-faithful counting mode, the children a dropped container would have counted)
+                        const float behind = (cont_mask == 0 || (!sc.has_transparency && !rp.no_early_out)) ? 0.f : -__builtin_inff();
                         {
                             const int q0 = child_base >> 2, nq = (n + 3) >> 2;
                             unsigned acc = 0;
@@ -811,12 +823,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                                 const AS4 F16* pb = lq + q0 + q + 1;
                                 asm volatile("" : "+s"(pb));
                                 const F16 qb = *pb;                              // (array is padded)
-                                acc |= cull_hit4(qa, fox, foy, foz, fdx, fdy, fdz, fdd) << (4 * q);
+                                acc |= cull_hit4(qa, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << (4 * q);
                                 const AS4 F16* pa = lq + q0 + q + 2;
                                 asm volatile("" : "+s"(pa));
                                 qa = *pa;
                                 // (branch-free so both loads stay ahead of the math: past the end the bits are masked off)
-                                acc |= cull_hit4(qb, fox, foy, foz, fdx, fdy, fdz, fdd) << ((4 * (q + 1)) & 31);
+                                acc |= cull_hit4(qb, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << ((4 * (q + 1)) & 31);
                             }
                             cand = acc & (n >= 32 ? ~0u : ((1u << n) - 1u));
                         }
@@ -892,33 +904,41 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     // arrives with ONE batch of scalar loads — field-by-field access made the compiler wait five times in a row
                     typedef uint32_t U16 __attribute__((ext_vector_type(16)));
                     const AS4 U16* crp = (const AS4 U16*)(conts + (int)hdr[7] + __builtin_popcount(hdr[4] & ((1u << c) - 1u)));
-                    U16 ra = crp[0], rb = crp[1];
-                    {   // (both loads must be in flight before the first use: tie one element of each to an opaque point)
+                    U16 ra = crp[0], rb;
+                    if (!CSG) {
+                        // (both loads must be in flight before the first use: tie one element of each to an opaque point)
+                        rb = crp[1];
                         uint32_t e0 = ra[5], e1 = rb[8];
                         asm volatile("" : "+s"(e0), "+s"(e1));
                         ra[5] = e0; rb[8] = e1;
                     }
+                    // (scenes with CSG: a CSG root needs the first 64 bytes only, and the 16 scalar registers of the second load
+                    // would be live across the interpreter — there the second half is fetched when a GROUP is visited)
                     auto f64_of = [](uint32_t lo_, uint32_t hi_) { return __builtin_bit_cast(double, (uint64_t)lo_ | ((uint64_t)hi_ << 32)); };
                     const int cflags = (int)ra[5];
+                    // this lane's own pre-test of the child (the sweep's, recomputed: the candidate bits of a chunk do not survive
+                    // a descent); a lane takes part only if ITS ray may hit, whichever lane made the wave come here
+                    auto own_miss = [&]() {
+                        sync_level(level);
+                        Head ch = {};
+                        ch[4] = ra[0]; ch[5] = ra[1]; ch[6] = ra[2]; ch[7] = ra[3];
+                        return cull_miss(ch, fox, foy, foz, fdx, fdy, fdz, fdd, (!sc.has_transparency && !rp.no_early_out) ? 0.f : -__builtin_inff());
+                    };
                     if (CSG && (cflags & CONT_CSG)) {
                         if constexpr (CSG) {
-                            // (a CSG root's record: `list` = offset of its program in csg_prog, child_hdr[0] = its length, dwords)
-                            const int poff = (int)ra[4], plen = (int)rb[8];
-                            resume_at = act ? 0 : 0x7fffffff;
+                            const bool cmiss = own_miss();
+                            // (a CSG root's record: `list` = offset of its program in csg_prog, first word of `t` = its length, in dwords)
+                            const int poff = (int)ra[4], plen = (int)ra[6];
+                            resume_at = (act && !cmiss) ? 0 : 0x7fffffff;
                             cnt = 0; starts = 0; mids = 0;
                             interpret(poff, plen);
                         }
                         continue;
                     }
                     // ---- Groups::local_intersect (group.rs:64-75): pre-test, ray into the group's space, bounds
-                    sync_level(level);
+                    if (CSG) rb = crp[1];
                     EV(RTX_EV_OP_SLOTS, 1);
-                    bool test = act;
-                    {
-                        Head ch = {};
-                        ch[4] = ra[0]; ch[5] = ra[1]; ch[6] = ra[2]; ch[7] = ra[3];
-                        if (cull_miss(ch, fox, foy, foz, fdx, fdy, fdz, fdd)) test = false;
-                    }
+                    const bool test = act && !own_miss();
                     if (__any(test)) {
                         const int xf = CONT_XF(cflags);
                         V3 lo, ld;

@@ -671,3 +671,36 @@ print("ok")
     env["PYTHONPATH"] = os.pathsep.join([here, os.path.join(here, "..", "ray-tracer_amd", "python"), os.path.join(here, "..", "tools")])
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+FAR = [("S4", 240, 136, {}), ("S3", 200, 112, dict(levels=2, per_leaf=6)), ("S5", 240, 136, {})]
+FAR_VARIANTS = [dict(world_offset=(1.0e4, -2.5e3, 7.0e3)), dict(world_offset=(1.0e6, 1.0e6, -1.0e6)),
+                dict(wrap=(1.0e-3, (0.0, 0.0, 0.0))), dict(wrap=(1.0e3, (5.0e3, -2.0e3, 7.0e3)))]
+
+
+@pytest.mark.parametrize("name,w,h,kw", FAR, ids=[c[0] for c in FAR])
+def test_scenes_far_from_the_origin_and_in_scaled_groups(ctx, name, w, h, kw):
+    """The conservative f32 pre-tests (bounding spheres in rtx_api.hip: cull_sphere, CULL_KAPPA; the behind-the-origin test)
+    must stay conservative when coordinates are large against the distances that matter: the whole scene, lights and
+    camera moved by 1e4 and 1e6 (every root object's transform gets the translation), and the whole scene inside one root
+    group scaled by 1e-3 / by 1e3 and moved.  Same checks as the scene parity test, against the oracle on the same worlds."""
+    import ora
+    import rtapi
+    import rtx
+    import yaml_scene
+    text = parity.scene_text(name, w, h, **kw)
+    for var in FAR_VARIANTS:
+        pw, pcs = yaml_scene.load(text, rtx.API, **var)
+        ow, ocs = yaml_scene.load(text, ora.API, **var)
+        gpu = ctx.render(pw, pcs[0], 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+        cpu = ora.render(ow, ocs[0], 5, threads=8)
+        r = parity.assert_parity(gpu, cpu, "%s %s" % (name, var))
+        assert (gpu["hit"] >= 0).mean() > 0.2, (name, var)          # the scene is in view (a plane inside the wrap group is clipped
+                                                                    # to the group's box: bounds.rs:29-40 gives it no bounds)
+        if r["tie_pixels"] == 0:
+            gs, cs = gpu["stats"], cpu["stats"]
+            assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), (name, var, r)
+            ge, ce = gs.events(), cs.events()
+            assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}, (name, var)
+        fast = ctx.render(pw, pcs[0], 5)
+        assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), (name, var)

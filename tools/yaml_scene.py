@@ -120,8 +120,14 @@ def _str(e):
 
 
 class Loader:
-    def __init__(self, api):
+    def __init__(self, api, world_offset=None, wrap=None):
+        """world_offset (dx, dy, dz): every root object, light and camera is moved by it (test scenes far from the origin);
+        wrap (scale, (dx, dy, dz)): all root objects go into ONE extra root group with transform translate . scale, lights and
+        camera are mapped the same way (test scenes inside a strongly scaled / far translated group).  Not part of the DSL."""
         self.api = api
+        self.world_offset = world_offset
+        self.wrap = wrap
+        self.wrap_group = None
         self.world = api.world_new()
         self.cameras = []
         self.materials = {}
@@ -141,13 +147,37 @@ class Loader:
                 ops.append((k, f64_expr(v)))
         return self.api.compose(ops)
 
+    def map_point(self, p):
+        p = list(p)
+        if self.wrap is not None:
+            sc, off = self.wrap
+            p = [p[k] * sc + off[k] for k in range(3)]
+        if self.world_offset is not None:
+            p = [p[k] + self.world_offset[k] for k in range(3)]
+        return p
+
+    def root_transform(self, t):
+        if self.world_offset is not None:
+            t = self.api.mat_mul(self.api.translation(*self.world_offset), t)
+        return t
+
+    def add_root(self, obj):
+        if self.wrap is None:
+            self.world.add_object_to_scene(obj)
+            return
+        if self.wrap_group is None:
+            sc, off = self.wrap
+            self.wrap_group = self.world.add_group(self.api.compose([("scale", [sc, sc, sc]), ("translate", list(off))]))
+            self.world.add_object_to_scene((OBJ_GROUP, self.wrap_group))
+        self.world.set_group_of(obj, self.wrap_group)
+
     def camera(self, e):                            # yaml.rs:75-87
         w, h = classify(e["width"]), classify(e["height"])
         if w[0] != "int" or h[0] != "int":
             raise SceneError("camera size must be integer")
         cam = self.api.camera(w[1], h[1], f64_expr(e["field-of-view"]))
         if "up" in e:
-            cam.transform = self.api.view_transform(f64_tuple(e["from"]), f64_tuple(e["to"]), f64_tuple(e["up"]))
+            cam.transform = self.api.view_transform(self.map_point(f64_tuple(e["from"])), self.map_point(f64_tuple(e["to"])), f64_tuple(e["up"]))
         self.cameras.append(cam)
 
     def pattern(self, e, m):                        # yaml.rs:427-464
@@ -194,16 +224,16 @@ class Loader:
                 parent = self.groups[_str(v)]
             elif k == "transform":
                 t = self.transform(v)
-        g = self.world.add_group(t)
+        g = self.world.add_group(t if parent is not None else self.root_transform(t))
         if parent is not None:
             self.world.set_group_of((OBJ_GROUP, g), parent)
         else:
-            self.world.add_object_to_scene((OBJ_GROUP, g))
+            self.add_root((OBJ_GROUP, g))
         if name is None:
             raise SceneError("Group without name.")
         self.groups[name] = g
 
-    def shape_properties(self, kind, e):            # yaml.rs:108-137
+    def shape_properties(self, kind, e, root=False):            # yaml.rs:108-137
         m, t, grp = self.api.material(), self.api.identity(), None
         for k, v in e.items():
             if k == "material":
@@ -212,14 +242,16 @@ class Loader:
                 t = self.transform(v)
             elif k == "group":
                 grp = v if isinstance(v, str) and classify(v)[0] == "str" else None
+        if root and grp is None:
+            t = self.root_transform(t)
         return self.world.add_shape(kind, m, t), grp
 
     def toplevel_shape(self, kind, e):              # yaml.rs:95-106
-        s, grp = self.shape_properties(kind, e)
+        s, grp = self.shape_properties(kind, e, root=True)
         if grp is not None:
             self.world.set_group_of((OBJ_SHAPE, s), self.groups[grp])
         else:
-            self.world.add_object_to_scene((OBJ_SHAPE, s))
+            self.add_root((OBJ_SHAPE, s))
 
     def obj(self, e):                               # yaml.rs:139-171
         what = _str(e["add"])
@@ -233,7 +265,7 @@ class Loader:
             return (OBJ_CSG, self.csg(e))
         raise SceneError("bad CSG operand %r" % what)
 
-    def csg(self, e):                               # yaml.rs:173-216
+    def csg(self, e, root=False):                   # yaml.rs:173-216
         t, op, operands = self.api.identity(), None, None
         for k, v in e.items():
             if k == "operator":
@@ -247,7 +279,7 @@ class Loader:
                 operands = (l, r)
         if op is None or operands is None:
             raise SceneError("CSG needs operator and operands")
-        return self.world.add_csg(op, operands[0], operands[1], t)
+        return self.world.add_csg(op, operands[0], operands[1], self.root_transform(t) if root else t)
 
     def load(self, text):                           # yaml.rs:22-73
         doc = yaml.load(text, Loader=yaml.BaseLoader)
@@ -258,11 +290,11 @@ class Loader:
                 if what == "camera":
                     self.camera(e)
                 elif what == "light":
-                    self.world.add_light(f64_tuple(e["at"]), f64_tuple(e["intensity"]))
+                    self.world.add_light(self.map_point(f64_tuple(e["at"])), f64_tuple(e["intensity"]))
                 elif what in shapes:
                     self.toplevel_shape(shapes[what], e)
                 elif what == "csg":
-                    self.world.add_object_to_scene((OBJ_CSG, self.csg(e)))
+                    self.add_root((OBJ_CSG, self.csg(e, root=True)))
             elif "define" in e:
                 what = _str(e["define"])
                 if what == "material":
@@ -273,5 +305,5 @@ class Loader:
         return self.world, self.cameras
 
 
-def load(text, api):
-    return Loader(api).load(text)
+def load(text, api, world_offset=None, wrap=None):
+    return Loader(api, world_offset, wrap).load(text)
