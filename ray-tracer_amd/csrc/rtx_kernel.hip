@@ -170,13 +170,16 @@ DI unsigned wave_sum(unsigned v) {
 // One shade_hit (world.rs:127-149) waiting for its children.  Frames live in scratch (indexed by the
 // per-lane stack pointer) and hold only what the parent needs when a child returns; the context of the
 // hit being shaded right now (point, normal, eye vector) stays in registers instead.
-struct Frame {
+struct Frame {           // 40 bytes
     double s[3];         // surface; once the reflected child is back: surface + reflected [* reflectance]
-    double R, refl, transp;
-    double o2[3], d2[3]; // the refraction ray (world.rs:186-188) while the reflected child is traced
+    double R;            // Schlick reflectance (world.rs:304-323), computed before descending
     int32_t flags;       // FR_*
-    int32_t remaining;   // the `remaining` this shade_hit was called with
+    int32_t rem_mat;     // the `remaining` this shade_hit was called with (4 bits) | material of the hit << 4: the
+                         //   coefficients `reflective` / `transparency` are read from the material when a child returns
 };
+// the refraction ray (world.rs:186-188) of a frame while its reflected child is traced: written only by hits that have BOTH
+// children (kept apart from the frames so that the other hits do not pay for it)
+struct PendRay { double o[3], d[3]; };
 enum {
     FR_REFL = 1,         // the first child is the reflected ray (else: the only child is the refracted ray)
     FR_REFR_PENDING = 2, // a refraction ray waits in o2/d2
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     // ---- state that survives a traversal (everything else is rebuilt or re-read):
     int remaining = rp.max_depth;         // budget of the color_at call being traced
     int sp = 0;                           // frames below sp wait for children
+    PendRay prays[RTX_MAX_DEPTH + 1];
     Frame frames[RTX_MAX_DEPTH + 1];      // + 1: the hit at budget 0 (sp == max_depth) still parks its partial light sum in frames[sp]
     bool primary = !spare;                // (the spare lanes of a split wave never trace a primary ray)
     // the hit being shaded while its shadow rays are traced (PreparedComputations, world.rs:225-256)
@@ -1208,12 +1212,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             } else {
                 Frame& f = frames[sp];
                 f.s[0] = sr; f.s[1] = sg; f.s[2] = sb;
-                f.R = R; f.refl = refl; f.transp = transp;
-                f.remaining = remaining;
+                f.R = R;
+                f.rem_mat = remaining | (hmat << 4);
                 if (do_refl) {
                     if (SPLIT && do_refr) pend |= 1u << sp;
                     f.flags = FR_REFL | (do_refr ? FR_REFR_PENDING : 0) | (both ? FR_BOTH : 0);
-                    if (do_refr) { f.o2[0] = fo.x; f.o2[1] = fo.y; f.o2[2] = fo.z; f.d2[0] = fd.x; f.d2[1] = fd.y; f.d2[2] = fd.z; }
+                    if (do_refr) { PendRay& pr = prays[sp]; pr.o[0] = fo.x; pr.o[1] = fo.y; pr.o[2] = fo.z; pr.d[0] = fd.x; pr.d[1] = fd.y; pr.d[2] = fd.z; }
                     nro = hp + nv * 1e-10;                                        // over_point
                     nrd = reflect3(neg(eyev), nv);                                // reflectv (world.rs:251)
                 } else {
@@ -1255,8 +1259,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         Frame& f = frames[level];
                         double* hs = lds_rays + target;            // the helper's ray slot 0
                         double* hd = lds_rays + sc.n_org_slots * LDS_HALF_DOUBLES + target;
-                        hs[0] = f.o2[0]; hs[64] = f.o2[1]; hs[128] = f.o2[2]; hd[0] = f.d2[0]; hd[64] = f.d2[1]; hd[128] = f.d2[2];
-                        mb_rem[target] = f.remaining - 1;
+                        const PendRay& pr = prays[level];
+                        hs[0] = pr.o[0]; hs[64] = pr.o[1]; hs[128] = pr.o[2]; hd[0] = pr.d[0]; hd[64] = pr.d[1]; hd[128] = pr.d[2];
+                        mb_rem[target] = (f.rem_mat & 15) - 1;
                         // (the helper reads its ray slot with plain loads: order the stores above before the flag, and see
                         // the acquire fence at the top of the trace)
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1298,16 +1303,17 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 Frame& f = frames[sp - 1];
                 const int fl = f.flags;
                 const double R = f.R;
+                const MaterialRec* fm = sc.materials + (f.rem_mat >> 4);
                 double s0 = f.s[0], s1 = f.s[1], s2 = f.s[2];
                 if (fl & FR_SECOND) {
                     // refracted child finished (world.rs:190-192); f.s already holds surface + reflected [* R]
-                    const double transp = f.transp;
+                    const double transp = fm->transparency;
                     rr = rr * transp; rg = rg * transp; rb = rb * transp;
                     if (fl & FR_BOTH) { rr = s0 + rr * (1.0 - R); rg = s1 + rg * (1.0 - R); rb = s2 + rb * (1.0 - R); }
                     else { rr = s0 + rr; rg = s1 + rg; rb = s2 + rb; }
                 } else if (fl & FR_REFL) {
                     // reflected child finished (world.rs:160-162): surface + reflected [* reflectance] ...
-                    const double refl = f.refl;
+                    const double refl = fm->reflective;
                     double ar = rr * refl, ag = rg * refl, ab = rb * refl;
                     if (fl & FR_BOTH) { s0 = s0 + ar * R; s1 = s1 + ag * R; s2 = s2 + ab * R; }
                     else { s0 = s0 + ar; s1 = s1 + ag; s2 = s2 + ab; }
@@ -1315,9 +1321,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         if (SPLIT) pend &= ~(1u << (sp - 1));
                         f.s[0] = s0; f.s[1] = s1; f.s[2] = s2;
                         f.flags = fl | FR_SECOND;
-                        nro = V3{f.o2[0], f.o2[1], f.o2[2]}; nrd = V3{f.d2[0], f.d2[1], f.d2[2]};
+                        { const PendRay& pr = prays[sp - 1]; nro = V3{pr.o[0], pr.o[1], pr.o[2]}; nrd = V3{pr.d[0], pr.d[1], pr.d[2]}; }
                         newray = true;
-                        remaining = f.remaining - 1;
+                        remaining = (f.rem_mat & 15) - 1;
                         mode = MODE_RADIANCE;
                         returning = false;
                         continue;
@@ -1337,7 +1343,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     else { rr = s0 + 0.0; rg = s1 + 0.0; rb = s2 + 0.0; }
                 } else {
                     // the only child was the refracted ray; reflected is black
-                    const double transp = f.transp;
+                    const double transp = fm->transparency;
                     rr = rr * transp; rg = rg * transp; rb = rb * transp;
                     if (fl & FR_BOTH) { rr = s0 + 0.0 * R + rr * (1.0 - R); rg = s1 + 0.0 * R + rg * (1.0 - R); rb = s2 + 0.0 * R + rb * (1.0 - R); }
                     else { rr = s0 + 0.0 + rr; rg = s1 + 0.0 + rg; rb = s2 + 0.0 + rb; }
