@@ -86,10 +86,13 @@ pub struct RtxStats {
     pub ev: [u64; 24],
     pub overflow_pixels: u64,
     pub kernel_ms: f64,
+    pub rays_shadow_skipped: u64,
 }
 
 pub enum RtxCtx {}
 pub enum RtxScene {}
+pub enum RtxComm {}
+pub const RTX_COMM_ID_BYTES: usize = 128;
 
 #[link(name = "rtx_hip")]
 extern "C" {
@@ -102,6 +105,26 @@ extern "C" {
     pub fn rtx_render_batch(ctx: *mut RtxCtx, scene: *const RtxScene, cams: *const RtxCamera, n_cams: i32,
                             max_depth: i32, flags: u32, rgb: *const *mut u8, hit: *const *mut i32,
                             stats: *mut RtxStats) -> i32;
+    pub fn rtx_render_device(ctx: *mut RtxCtx, scene: *const RtxScene, cam: *const RtxCamera, max_depth: i32,
+                             bands: RtxBands, flags: u32, d_rgb: *mut std::ffi::c_void, d_hit: *mut std::ffi::c_void,
+                             stream: *mut std::ffi::c_void, stats: *mut RtxStats) -> i32;
+    pub fn rtx_render_device_noalloc(ctx: *mut RtxCtx, scene: *const RtxScene, cam: *const RtxCamera, max_depth: i32,
+                                     bands: RtxBands, flags: u32, d_rgb: *mut std::ffi::c_void,
+                                     d_hit: *mut std::ffi::c_void, stream: *mut std::ffi::c_void) -> i32;
+    pub fn rtx_ctx_poll(ctx: *mut RtxCtx, wait: i32) -> i32;
+    pub fn rtx_set_option(ctx: *mut RtxCtx, name: *const c_char, value: i32) -> i32;
+    // one frame on N GPUs: tile bands per GPU + one RCCL all-gather + de-interleave, all inside the library
+    pub fn rtx_comm_unique_id(id: *mut std::ffi::c_void) -> i32;
+    pub fn rtx_comm_init_rank(ctx: *mut RtxCtx, id: *const std::ffi::c_void, rank: i32, world_size: i32,
+                              out: *mut *mut RtxComm) -> i32;
+    pub fn rtx_comm_init_all(ctxs: *const *mut RtxCtx, n: i32, out: *mut *mut RtxComm) -> i32;
+    pub fn rtx_comm_destroy(comm: *mut RtxComm);
+    pub fn rtx_render_gathered(comm: *mut RtxComm, scene: *const RtxScene, cam: *const RtxCamera, max_depth: i32,
+                               flags: u32, d_frame: *mut std::ffi::c_void, d_hit_frame: *mut std::ffi::c_void,
+                               stream: *mut std::ffi::c_void, stats: *mut RtxStats) -> i32;
+    pub fn rtx_comm_wait(comm: *mut RtxComm, stream: *mut std::ffi::c_void) -> i32;
+    pub fn rtx_render_multi(comms: *const *mut RtxComm, scenes: *const *const RtxScene, n: i32, cam: *const RtxCamera,
+                            max_depth: i32, flags: u32, rgb: *mut u8, hit: *mut i32, stats: *mut RtxStats) -> i32;
     pub fn rtx_strerror(code: i32) -> *const c_char;
     pub fn rtx_last_error(ctx: *const RtxCtx) -> *const c_char;
 }

@@ -33,10 +33,15 @@ def compare(gpu, cpu):
     )
 
 
-def assert_parity(gpu, cpu, label=""):
+def assert_parity(gpu, cpu, label="", max_tie_frac=0.005):
+    """The acceptance bar.  Pixels the oracle flags as EPSILON ties (a decision within 1e-11 relative) are exempt from
+    the id check, so the exemption itself is bounded: at most max_tie_frac of the pixels (and never fewer than 8 allowed,
+    for tiny images) may be flagged — a regression that inflated the tie flags would otherwise hide id mismatches.  The
+    committed scenes S1-S5 are checked with max_tie_frac = 0.  `id_mismatch_incl_ties` is reported for the logs."""
     r = compare(gpu, cpu)
     assert r["id_mismatch"] == 0, (label, r)
     assert r["within1"] >= 0.999, (label, r)
+    assert r["tie_pixels"] <= (max(8, int(max_tie_frac * r["n"])) if max_tie_frac > 0 else 0), (label, "too many tie pixels", r)
     return r
 
 

@@ -61,7 +61,8 @@ def test_scene_parity(ctx, name, w, h, kw):
     (pw, pc), (ow, oc) = parity.build_both(text)
     gpu = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
     cpu = ora.render(ow, oc, 5, threads=8)
-    r = parity.assert_parity(gpu, cpu, name)
+    r = parity.assert_parity(gpu, cpu, name)                        # tie pixels bounded at 0.5 % ...
+    assert r["id_mismatch_incl_ties"] == 0                          # ... and on the committed scenes not even they differ
     gs, cs = gpu["stats"], cpu["stats"]
     assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), r
     ge, ce = gs.events(), cs.events()
@@ -346,7 +347,7 @@ def test_randomized_scene_files_parity(ctx):
     import rtx
     import yaml_scene
     rng = np.random.default_rng(20261111)
-    done = skipped = ties = 0
+    done = skipped = ties = px = tie_mis = 0
     for i in range(40):
         text = fuzz_scenes.make(rng)
         depth = (5, 0, 1, 3, 8)[i % 5]
@@ -359,7 +360,10 @@ def test_randomized_scene_files_parity(ctx):
             continue
         ow, ocs = yaml_scene.load(text, ora.API)
         cpu = ora.render(ow, ocs[0], depth, threads=8)
-        r = parity.assert_parity(gpu, cpu, "generated scene %d depth %d\n%s" % (i, depth, text))
+        # (random scenes do produce coincident surfaces — a plane through a CSG face, touching operands: per scene the tie
+        # exemption is bounded at 25 %, over the whole run at 3 %, and mismatches INSIDE tie pixels are counted below)
+        r = parity.assert_parity(gpu, cpu, "generated scene %d depth %d\n%s" % (i, depth, text), max_tie_frac=0.25)
+        px += r["n"]; tie_mis += r["id_mismatch_incl_ties"]
         gs, cs = gpu["stats"], cpu["stats"]
         if r["tie_pixels"] == 0:
             # (a tie pixel may legitimately follow another branch of the ray tree, so its rays differ)
@@ -370,6 +374,8 @@ def test_randomized_scene_files_parity(ctx):
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
         ties += r["tie_pixels"]; done += 1
     assert done >= 30, (done, skipped)
+    print("randomized scene files: %d scenes, %d pixels, %d tie pixels, %d id mismatches inside them" % (done, px, ties, tie_mis))
+    assert ties <= 0.03 * px and tie_mis <= 0.02 * max(ties, 1) + 2, (ties, px, tie_mis)
 
 
 def test_randomized_api_scene_graphs_parity(ctx):
@@ -381,7 +387,7 @@ def test_randomized_api_scene_graphs_parity(ctx):
     import rtapi
     import rtx
     rng = np.random.default_rng(20261112)
-    done = 0
+    done = px = ties = tie_mis = 0
     for i in range(40):
         p = fuzz_api.plan(rng)
         depth = (5, 0, 2, 8)[i % 4]
@@ -393,7 +399,14 @@ def test_randomized_api_scene_graphs_parity(ctx):
             continue
         ow, oc = fuzz_api.build(ora.API, p)
         cpu = ora.render(ow, oc, depth, threads=8)
-        r = parity.assert_parity(gpu, cpu, "generated graph %d depth %d" % (i, depth))
+        # (random graphs contain coincident surfaces — the same plane twice, touching CSG operands — whose every pixel is a
+        # tie: a scene with more than 25 % tie pixels must then match WITHOUT the exemption; the others are bounded per
+        # scene and, below, over the whole run)
+        r = parity.assert_parity(gpu, cpu, "generated graph %d depth %d" % (i, depth), max_tie_frac=1.0)
+        if r["tie_pixels"] > 0.25 * r["n"]:
+            assert r["id_mismatch_incl_ties"] == 0, (i, r)
+        else:
+            px += r["n"]; ties += r["tie_pixels"]; tie_mis += r["id_mismatch_incl_ties"]
         if r["tie_pixels"] == 0:
             gs, cs = gpu["stats"], cpu["stats"]
             assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), (i, r)
@@ -403,6 +416,8 @@ def test_randomized_api_scene_graphs_parity(ctx):
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
         done += 1
     assert done >= 30
+    print("randomized scene graphs: %d scenes, %d pixels, %d tie pixels, %d id mismatches inside them" % (done, px, ties, tie_mis))
+    assert ties <= 0.03 * px and tie_mis <= 0.02 * max(ties, 1) + 2, (ties, px, tie_mis)
 
 
 def test_kernel_limits_are_reported_not_truncated(ctx):
@@ -694,7 +709,11 @@ def test_scenes_far_from_the_origin_and_in_scaled_groups(ctx, name, w, h, kw):
         ow, ocs = yaml_scene.load(text, ora.API, **var)
         gpu = ctx.render(pw, pcs[0], 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
         cpu = ora.render(ow, ocs[0], 5, threads=8)
-        r = parity.assert_parity(gpu, cpu, "%s %s" % (name, var))
+        # (1e6 away from the origin one ulp of a coordinate is 1.2e-10, the size of the reference's EPSILON offsets
+        # (world.rs:298-300): surface acne, i.e. tie pixels, is then expected — the exemption is bounded at 30 % there)
+        far = max(abs(v) for v in var.get("world_offset", (0,))) >= 1e6
+        r = parity.assert_parity(gpu, cpu, "%s %s" % (name, var), max_tie_frac=0.3 if far else 0.005)
+        print(name, var, "tie pixels", r["tie_pixels"], "id mismatches incl. ties", r["id_mismatch_incl_ties"])
         assert (gpu["hit"] >= 0).mean() > 0.2, (name, var)          # the scene is in view (a plane inside the wrap group is clipped
                                                                     # to the group's box: bounds.rs:29-40 gives it no bounds)
         if r["tie_pixels"] == 0:
@@ -704,3 +723,30 @@ def test_scenes_far_from_the_origin_and_in_scaled_groups(ctx, name, w, h, kw):
             assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}, (name, var)
         fast = ctx.render(pw, pcs[0], 5)
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), (name, var)
+
+
+def test_scene_description_in_the_rust_shims_node_order(ctx):
+    """N1: integration/rust/src/flatten.rs numbers the nodes shapes-first, then groups, then CSGs, with one material per
+    shape; the C++ host mirror numbers them in creation order with the same materials.  The C ABI must not care: the
+    description rebuilt in flatten.rs's order (tests/rust_order.py, from the world's canonical dump) through raw
+    rtx_scene_create renders the same image, ids and counts as rtxh_render, on a scene file with groups and CSG and on
+    the API-built torture scene (CSG inside groups, a group as a CSG operand, empty groups)."""
+    import rtx
+    import rust_order
+    import torture
+    worlds = []
+    pw, pcs = rtx.load_yaml(parity.scene_text("S5", 200, 120))
+    worlds.append((pw, pcs[0]))
+    pw, pcs = rtx.load_yaml(parity.scene_text("S3", 160, 96, levels=2, per_leaf=5))
+    worlds.append((pw, pcs[0]))
+    worlds.append(torture.build(rtx.API))
+    for k, (w, cam) in enumerate(worlds):
+        want = ctx.render(w, cam, 5, flags=rtx.F_COUNT_EVENTS)
+        desc, keep = rust_order.desc_in_rust_order(w)
+        sc = rtx.Scene(ctx, desc=desc)
+        try:
+            got = sc.render(cam, 5, flags=rtx.F_COUNT_EVENTS)
+        finally:
+            sc.close()
+        assert np.array_equal(got["rgb"], want["rgb"]) and np.array_equal(got["hit"], want["hit"]), k
+        assert got["stats"].rays == want["stats"].rays and got["stats"].events() == want["stats"].events(), k

@@ -329,3 +329,92 @@ def test_yaml_loader_fuzz_against_python_loader():
             assert bytes(a)[:8] == bytes(b)[:8]
         n_ok += 1; n_cam += len(c1)
     assert 240 < n_ok < 300 and n_cam > 50
+
+
+def _rust_structs(path):
+    """#[repr(C)] structs of integration/rust/src/gpu.rs -> {name: [(field, rust type)]}"""
+    import re
+    src = open(path).read()
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+)\s*\{(.*?)\n\}", src, re.S):
+        fields = re.findall(r"pub (\w+):\s*([^,\n]+),", m.group(2))
+        out[m.group(1)] = [(f, t.strip()) for f, t in fields]
+    return out
+
+
+def _repr_c_layout(fields):
+    """size, {field: offset} under Rust's repr(C) rules (= the C ABI's) on x86-64"""
+    import re
+    prim = {"i32": (4, 4), "u32": (4, 4), "f64": (8, 8), "u64": (8, 8), "i64": (8, 8), "u8": (1, 1)}
+
+    def size_align(t):
+        if t.startswith("*"):
+            return 8, 8
+        m = re.match(r"\[(\w+);\s*(\d+)\]", t)
+        if m:
+            s, a = prim[m.group(1)]
+            return s * int(m.group(2)), a
+        return prim[t]
+    off, offs, amax = 0, {}, 1
+    for name, t in fields:
+        s, a = size_align(t)
+        off = (off + a - 1) // a * a
+        offs[name] = off
+        off += s
+        amax = max(amax, a)
+    return (off + amax - 1) // amax * amax, offs
+
+
+def test_rust_binding_layouts_match_the_c_header(tmp_path):
+    """N1: the Rust shim in integration/rust cannot be compiled here (no rustc), but its #[repr(C)] structs
+    can be pinned: the layout Rust's repr(C) rules give each struct in gpu.rs (sizes and field offsets, computed here) must
+    equal what gcc lays out for the struct of the same role in include/rtx.h (sizeof / offsetof from a compiled C
+    program), field by field and in the same order; and every function of its extern "C" block must be exported by
+    librtx_hip.so with the same number of parameters as the prototype in rtx.h."""
+    import re
+    import subprocess
+    import rtx
+    root = ROOT
+    rs = _rust_structs(os.path.join(root, "integration", "rust", "src", "gpu.rs"))
+    pairs = {"RtxMaterial": "rtx_material", "RtxSceneDesc": "rtx_scene_desc", "RtxCamera": "rtx_camera",
+             "RtxBands": "rtx_bands", "RtxStats": "rtx_stats"}
+    assert set(pairs) <= set(rs), sorted(rs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rtx.h"', 'int main(void) {']
+    for r, c in pairs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (r, c))
+        for f, _ in rs[r]:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (r, f, c, f))      # a field missing in C fails to compile
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        a, b, v = line.split()
+        got[(a, b)] = int(v)
+    header = open(os.path.join(root, "include", "rtx.h")).read()
+    for r, c in pairs.items():
+        size, offs = _repr_c_layout(rs[r])
+        assert got[(r, "size")] == size, (r, got[(r, "size")], size)
+        for f, o in offs.items():
+            assert got[(r, f)] == o, (r, f, got[(r, f)], o)
+        # same number of fields: nothing of the C struct is missing on the Rust side
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (c, c), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_c = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert n_c == len(rs[r]), (r, n_c, len(rs[r]))
+    # the extern "C" block against the header's prototypes and the library's exports
+    gpu_rs = open(os.path.join(root, "integration", "rust", "src", "gpu.rs")).read()
+    block = gpu_rs[gpu_rs.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    fns = re.findall(r"pub fn (\w+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", block, re.S)
+    assert len(fns) >= 15
+    flat = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, args in fns:
+        getattr(rtx.LIB, name)                                                 # exported
+        proto = re.search(r"\b%s\s*\((.*?)\);" % name, flat, re.S)
+        assert proto, name
+        c_args = [a for a in proto.group(1).split(",") if a.strip() and a.strip() != "void"]
+        r_args = [a for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(r_args), (name, c_args, r_args)
