@@ -497,9 +497,13 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // closest hit: smallest (t, op); innermost open containers: largest (t, op)
         auto closer = [&](double t, int op) { return best_op < 0 || t < best_t || (t == best_t && op < best_op); };
         auto later = [&](double t, int op, double ct, int cs) { return t > ct || (t == ct && op > cs); };
+        // (written with selects on the VALUES: as two branches storing into c1 / c2 the compiler turned the four variables
+        // into an array in scratch addressed through a selected pointer — a memory round trip per negative-t entry)
         auto enter = [&](double t, int op) {
-            if (later(t, op, c1t, c1s)) { c2t = c1t; c2s = c1s; c1t = t; c1s = op; }
-            else if (later(t, op, c2t, c2s)) { c2t = t; c2s = op; }
+            const bool a = later(t, op, c1t, c1s);
+            const bool b = !a && later(t, op, c2t, c2s);
+            c2t = a ? c1t : (b ? t : c2t); c2s = a ? c1s : (b ? op : c2s);
+            c1t = a ? t : c1t; c1s = a ? op : c1s;
         };
         // feed the hits of one shape (sorted, k <= 2) into the running state
         auto feed = [&](int k, double t0, double t1, int shape) {

@@ -11,6 +11,10 @@
 #ifndef RTX_POW_H
 #define RTX_POW_H
 
+// (out of line on purpose: inlined, the library pow's ~17 polynomial constants were hoisted to the kernel's prologue and
+// spilled there by every wave — 34 spilled registers for a path scene files never take)
+__device__ __attribute__((noinline)) double rtx_lib_pow(double x, double y) { return pow(x, y); }
+
 __device__ __forceinline__ double rtx_spec_pow(double x, double y) {
     double r;
     if (__builtin_trunc(y) == y && y >= 0.0 && y <= 4096.0) {
@@ -23,7 +27,7 @@ __device__ __forceinline__ double rtx_spec_pow(double x, double y) {
             if (n) b *= b;
         }
     } else {
-        r = pow(x, y);
+        r = rtx_lib_pow(x, y);
     }
     return r;
 }
