@@ -254,6 +254,7 @@ struct ListBuilder {
     std::vector<ListChunk> chunks;
     std::vector<ChunkCounts> counts;
     std::vector<float> cull;          // 4 floats per child slot, pair-interleaved per quad
+    std::vector<float> quad;          // per chunk 8 spheres (one per quad of children), same layout: 32 floats
     std::vector<int32_t> lops;
     std::vector<ContRec> conts;
     explicit ListBuilder(const std::vector<OpRec>& o) : ops(o) {}
@@ -312,6 +313,33 @@ struct ListBuilder {
                 }
             }
             ch.op0 = consec ? kids[k0] : -1;
+            // bounding spheres of the chunk's quads; the two-level sweep pays on long lists only (a short list's quads are
+            // all touched by some lane of an incoherent wave anyway, and the extra test is then pure overhead)
+            if (quad.size() < (size_t)(first + c + 1) * 32) quad.resize((size_t)(first + c + 1) * 32, INFINITY);
+            for (int q = 0; q < 8; q++) {
+                float s4[4] = {0.f, 0.f, 0.f, INFINITY};
+                double cx = 0, cy = 0, cz = 0; int m = 0; bool fin = true;
+                for (int k = q * 4; k < q * 4 + 4 && k < ch.n; k++) {
+                    const float* cu = ops[kids[k0 + k]].cull;
+                    fin = fin && std::isfinite(cu[3]);
+                    cx += cu[0]; cy += cu[1]; cz += cu[2]; m++;
+                }
+                if (m > 0 && fin) {
+                    cx /= m; cy /= m; cz /= m;
+                    double R = 0.0;
+                    for (int k = q * 4; k < q * 4 + 4 && k < ch.n; k++) {
+                        const float* cu = ops[kids[k0 + k]].cull;
+                        const double dx = cu[0] - cx, dy = cu[1] - cy, dz = cu[2] - cz;
+                        R = std::fmax(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)cu[3]));
+                    }
+                    // (the children's radii already carry their f32 margins; the quad's centre is rounded to f32 once more)
+                    R = R * 1.001 + 1e-6 * std::sqrt(cx * cx + cy * cy + cz * cz) + 1e-30;
+                    const double r2 = R * R;
+                    if (std::isfinite(r2) && r2 < 1e30) { s4[0] = (float)cx; s4[1] = (float)cy; s4[2] = (float)cz; s4[3] = std::nextafterf((float)r2, INFINITY); }
+                }
+                for (int k = 0; k < 4; k++) quad[(size_t)(first + c) * 32 + (q / 2) * 8 + k * 2 + (q & 1)] = s4[k];
+            }
+            if (nchunks > 1) ch.n |= (int32_t)CHUNK_TWO_LEVEL;
             chunks[first + c] = ch; counts[first + c] = cn;
         }
         for (auto& g : groups) {
@@ -325,6 +353,7 @@ struct ListBuilder {
     void finish() {
         while (lops.size() % 4) lops.push_back(-1);
         cull.resize((lops.size() / 4 + 3) * 16, INFINITY);              // whole quads + padding for the look-ahead loads
+        quad.resize(chunks.size() * 32, INFINITY);
         if (conts.empty()) { ContRec r; std::memset(&r, 0, sizeof r); conts.push_back(r); }
     }
 };
@@ -407,7 +436,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static void release_scene_memory(rtx_scene* s) {
     (void)hipSetDevice(s->device);
     for (void** p : {&s->d_ops, &s->d_bodies, &s->d_shapes, &s->d_paths, &s->d_materials, &s->d_lights, &s->d_pairs,
-                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts}) {
+                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts, &s->d_quad}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -615,7 +644,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
             prog_max = std::max(prog_max, len);
         }
     if (prog.empty()) prog.resize(8, 0u);
-    if ((rc = upload(ctx, lb.chunks, &s->d_chunks)) || (rc = upload(ctx, lb.counts, &s->d_counts)) || (rc = upload(ctx, lb.cull, &s->d_lcull)) ||
+    if ((rc = upload(ctx, lb.chunks, &s->d_chunks)) || (rc = upload(ctx, lb.counts, &s->d_counts)) || (rc = upload(ctx, lb.cull, &s->d_lcull)) || (rc = upload(ctx, lb.quad, &s->d_quad)) ||
         (rc = upload(ctx, lb.lops, &s->d_lops)) || (rc = upload(ctx, lb.conts, &s->d_conts)) ||
         (rc = upload(ctx, prog, &s->d_pairs)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
@@ -624,7 +653,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         return rc;
     }
     s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.csg_prog = (const uint32_t*)s->d_pairs; s->dev.csg_prog_max = prog_max; s->dev.hits = (const HitRec*)s->d_shapes;
-    s->dev.chunks = (const ListChunk*)s->d_chunks; s->dev.chunk_counts = (const ChunkCounts*)s->d_counts; s->dev.list_cull = (const float*)s->d_lcull;
+    s->dev.chunks = (const ListChunk*)s->d_chunks; s->dev.chunk_counts = (const ChunkCounts*)s->d_counts; s->dev.list_cull = (const float*)s->d_lcull; s->dev.quad_cull = (const float*)s->d_quad;
     s->dev.list_ops = (const int32_t*)s->d_lops; s->dev.cont_recs = (const ContRec*)s->d_conts;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;

@@ -73,7 +73,7 @@ enum { CSGP_HEAD_DWORDS = 8, CSGP_SHAPE_DWORDS = 40, CSGP_BEGIN_GENERAL_DWORDS =
 // (packed f32 bounding-sphere pre-test over the chunk's quads) tells every lane which children it may hit;
 // shapes are then tested per lane, and only the containers that SOME lane may hit are visited at all.
 struct ListChunk {           // 32 bytes = one s_load_dwordx8
-    int32_t n;               // children in this chunk (1..32)
+    int32_t n;               // children in this chunk (1..32) | CHUNK_TWO_LEVEL: the chunk's quads have bounding spheres in quad_cull[]
     int32_t child_base;      // multiple of 4: list_ops[child_base + k], spheres at list_cull[child_base * 4 ...]
     uint32_t shape_mask;     // children with a per-lane exact test (spheres, cubes, planes with point division)
     uint32_t plane_mask;     // OPF_INLINE planes: wave-uniform exact test
@@ -82,7 +82,7 @@ struct ListChunk {           // 32 bytes = one s_load_dwordx8
     int32_t op0;             // >= 0: child k is op (op0 + k), no list_ops lookup needed
     int32_t cont_base;       // cont_recs[cont_base + r] = r-th container child of this chunk
 };
-#define LIST_KINDS_SHIFT 0
+#define CHUNK_TWO_LEVEL 0x100u
 struct __attribute__((aligned(128))) ContRec {   // 256 bytes; the kernel reads the first half with one batch of scalar loads
     // ---- first half (128 bytes): all a visit needs unless the transform is XF_GENERAL
     float cull[4];           // bounding sphere in parent space (same as the sweep's)
@@ -139,6 +139,7 @@ struct SceneDev {
     const ListChunk* chunks;  // chunk 0 = first chunk of the world's list
     const ChunkCounts* chunk_counts;
     const float* list_cull;   // quads of bounding spheres in list order: {cxA,cxB,cyA,cyB,czA,czB,r2A,r2B} x 2 per 4 children
+    const float* quad_cull;   // per chunk: the bounding spheres of its eight quads of children, 2 x 16 floats in the pair layout
     const int32_t* list_ops;  // op index per child slot
     const ContRec* cont_recs;
     const uint32_t* csg_prog; // the programs of all CSG roots (CSGP_* records below), walked from LDS by the kernel

@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     have_hdr = false;
                     if (__any(act)) {
                         TM(tm_other);
-                        const int n = (int)hdr[0], child_base = (int)hdr[1], op0 = (int)hdr[6];
+                        const int n = (int)(hdr[0] & 0xffu), child_base = (int)hdr[1], op0 = (int)hdr[6];
                         const unsigned shape_mask = hdr[2], plane_mask = hdr[3], cont_mask = hdr[4];
                         sync_level(level);
                         EV(RTX_EV_OP_SLOTS, n);
@@ -823,7 +823,37 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         // and the scene has transparent materials)
                         // (... and, in the reference-faithful counting mode, the children a dropped container would have counted)
                         const float behind = (cont_mask == 0 || (!sc.has_transparency && !rp.no_early_out)) ? 0.f : -__builtin_inff();
-                        {
+                        if (hdr[0] & CHUNK_TWO_LEVEL) {
+                            // ---- long lists (more than one chunk): the eight quads of the chunk have bounding spheres of their own
+                            // (two loads); only the quads SOME lane's ray may touch are swept, two per wait.  A coherent wave —
+                            // primary rays of one tile, their shadow rays — touches one or two quads of a chunk.
+                            const int q0 = child_base >> 2, nq = (n + 3) >> 2;
+                            const AS4 F16* sq = (const AS4 F16*)(uintptr_t)sc.quad_cull + 2 * chunk;
+                            F16 sa = sq[0];
+                            const AS4 F16* psb = sq + 1;
+                            asm volatile("" : "+s"(psb));
+                            const F16 sb = *psb;
+                            unsigned ql = cull_hit4(sa, fox, foy, foz, fdx, fdy, fdz, fdd, behind) | (cull_hit4(sb, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << 4);
+                            if (!act) ql = 0;
+                            unsigned qmask = 0;
+#pragma unroll
+                            for (int b = 0; b < 8; b++) if (__any((ql >> b) & 1u)) qmask |= 1u << b;
+                            qmask &= (1u << nq) - 1u;
+                            unsigned acc = 0;
+                            while (qmask != 0) {
+                                const int ia = __builtin_ctz(qmask);
+                                qmask &= qmask - 1;
+                                const int ib = qmask != 0 ? __builtin_ctz(qmask) : ia;
+                                qmask &= qmask - 1;                                  // (0 & -1 = 0)
+                                const AS4 F16* pa = lq + q0 + ia;
+                                const AS4 F16* pb = lq + q0 + ib;
+                                asm volatile("" : "+s"(pa), "+s"(pb));
+                                const F16 qa = *pa, qb = *pb;
+                                acc |= cull_hit4(qa, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << (4 * ia);
+                                acc |= cull_hit4(qb, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << (4 * ib);
+                            }
+                            cand = acc & (n >= 32 ? ~0u : ((1u << n) - 1u));
+                        } else {
                             const int q0 = child_base >> 2, nq = (n + 3) >> 2;
                             unsigned acc = 0;
                             F16 qa = lq[q0];
