@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -118,7 +119,8 @@ void cull_sphere(const double* inverse16, const double* lc, double lr, float* ou
 // compile-time view of one op (head + body); split into the two device arrays at upload
 struct OpRec {
     int32_t kind, level, skip, flags, shape, clevel, xf;
-    float cull[4];
+    float cull[4];       // bounding sphere from the node's own extent / its local bounds (what the reference's bounds test implies)
+    float cull_t[4];     // CSG: the tighter sphere of where SURVIVING hits can lie (extent_sphere below); else = cull
     double inv[12], w33, bounds[6];
 };
 
@@ -169,7 +171,40 @@ struct Compiler {
                 }
             }
         }
+        std::memcpy(o.cull_t, o.cull, sizeof o.cull);
         return o;
+    }
+
+    // Where can hits that SURVIVE a CSG's filter (csg.rs:94-136) lie?  Union: on either child; intersection: left hits inside
+    // the right child and right hits inside the left one, i.e. inside BOTH; difference: left hits outside the right child and
+    // right hits inside the left one, i.e. inside the LEFT child.  A ray that misses a bounding sphere of that region gets an
+    // empty list from the CSG (for the intersection and the difference: it has no hit on that child, so the in/out toggle the
+    // other child's hits depend on never flips).  The children's spheres (in the CSG's space) give a sphere of the region,
+    // often far tighter than the one around the CSG's bounds, which merge BOTH children's boxes whatever the operator
+    // (object_store.rs:373-384).  Used for the pre-tests only where reference-faithful node-visit counts are not asked for.
+    void extent_sphere(int node, int begin, int left, int right, int cop) {
+        const float* a = ops[left].cull_t; const float* b = ops[right].cull_t;
+        const bool fa = std::isfinite(a[3]), fb = std::isfinite(b[3]);
+        double c[3], r;
+        auto take = [&](const float* s) { c[0] = s[0]; c[1] = s[1]; c[2] = s[2]; r = std::sqrt((double)s[3]); };
+        if (cop == RTX_CSG_DIFFERENCE) { if (!fa) return; take(a); }
+        else if (cop == RTX_CSG_INTERSECTION) { if (!fa && !fb) return; take((fa && (!fb || a[3] <= b[3])) ? a : b); }
+        else {
+            if (!fa || !fb) return;
+            const double ra = std::sqrt((double)a[3]), rb = std::sqrt((double)b[3]);
+            const double dx = (double)b[0] - a[0], dy = (double)b[1] - a[1], dz = (double)b[2] - a[2];
+            const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (dist + rb <= ra) take(a);
+            else if (dist + ra <= rb) take(b);
+            else {
+                r = (dist + ra + rb) * 0.5;
+                const double f = (r - ra) / dist;
+                c[0] = a[0] + dx * f; c[1] = a[1] + dy * f; c[2] = a[2] + dz * f;
+            }
+        }
+        float t4[4];
+        cull_sphere(d->node_inverse + (size_t)node * 16, c, r * 1.0001, t4);
+        if (std::isfinite(t4[3]) && (!std::isfinite(ops[begin].cull[3]) || t4[3] < ops[begin].cull[3])) std::memcpy(ops[begin].cull_t, t4, sizeof t4);
     }
 
     // returns the number of list entries the subtree can produce (for the CSG capacity check)
@@ -233,9 +268,12 @@ struct Compiler {
             const int xf = ob.xf;
             org_depth += xf != XF_IDENTITY; dir_depth += xf == XF_GENERAL;
             max_org = std::max(max_org, org_depth); max_dir = std::max(max_dir, dir_depth);
+            const int left_op = (int)ops.size();
             entries += emit(d->children[fc], level + 1, true, cl + 1);
             OpRec om = make(-1, OPK_CSG_MID, level, f, cl); om.shape = cop; ops.push_back(om);
+            const int right_op = (int)ops.size();
             entries += emit(d->children[fc + 1], level + 1, true, cl + 1);
+            if (err == RTX_OK) extent_sphere(node, b, left_op, right_op, cop);
             org_depth -= xf != XF_IDENTITY; dir_depth -= xf == XF_GENERAL;
             stack.pop_back();
             OpRec oe = make(-1, OPK_CSG_END, level, f, cl); oe.shape = cop; ops.push_back(oe);
@@ -255,11 +293,12 @@ struct ListBuilder {
     std::vector<ChunkCounts> counts;
     std::vector<float> cull;          // 4 floats per child slot, pair-interleaved per quad
     std::vector<float> quad;          // per chunk 8 spheres (one per quad of children), same layout: 32 floats
+    std::vector<float> cull_t, quad_t;   // the same from the tighter CSG spheres (OpRec::cull_t)
     std::vector<int32_t> lops;
     std::vector<ContRec> conts;
     explicit ListBuilder(const std::vector<OpRec>& o) : ops(o) {}
 
-    void put_cull(size_t slot, const float* c4) {
+    static void put_cull(std::vector<float>& cull, size_t slot, const float* c4) {
         const size_t q = slot / 4, p = slot % 4;
         if (cull.size() < (q + 1) * 16) cull.resize((q + 1) * 16, INFINITY);
         for (int k = 0; k < 4; k++) cull[q * 16 + (p / 2) * 8 + k * 2 + (p & 1)] = c4[k];
@@ -291,13 +330,15 @@ struct ListBuilder {
                 const OpRec& o = ops[op];
                 if (op != kids[k0] + k) consec = false;
                 lops.push_back(op);
-                put_cull((size_t)ch.child_base + k, o.cull);
+                put_cull(cull, (size_t)ch.child_base + k, o.cull);
+                put_cull(cull_t, (size_t)ch.child_base + k, o.cull_t);
                 if (o.kind == OPK_GROUP_BEGIN || o.kind == OPK_CSG_BEGIN) {
                     ch.cont_mask |= 1u << k; cn.containers++;
                     ContRec r; std::memset(&r, 0, sizeof r);
                     std::memcpy(r.inv, o.inv, sizeof r.inv); r.w33 = o.w33; std::memcpy(r.bounds, o.bounds, sizeof r.bounds);
                     r.t[0] = o.inv[3]; r.t[1] = o.inv[7]; r.t[2] = o.inv[11];
-                    std::memcpy(r.cull, o.cull, sizeof r.cull);
+                    std::memcpy(r.cull, o.cull_t, sizeof r.cull);
+                    std::memcpy(r.cull_loose, o.cull, sizeof r.cull_loose);
                     r.op = op; r.skip = o.skip; r.list = -1;
                     bool ok = true;
                     for (int b = 0; b < 6; b++) ok = ok && (std::isinf(o.bounds[b]) || std::fabs(o.bounds[b]) <= 1e100);
@@ -315,12 +356,14 @@ struct ListBuilder {
             ch.op0 = consec ? kids[k0] : -1;
             // bounding spheres of the chunk's quads; the two-level sweep pays on long lists only (a short list's quads are
             // all touched by some lane of an incoherent wave anyway, and the extra test is then pure overhead)
+            for (int pass = 0; pass < 2; pass++) {
+            std::vector<float>& quad = pass == 0 ? this->quad : this->quad_t;
             if (quad.size() < (size_t)(first + c + 1) * 32) quad.resize((size_t)(first + c + 1) * 32, INFINITY);
             for (int q = 0; q < 8; q++) {
                 float s4[4] = {0.f, 0.f, 0.f, INFINITY};
                 double cx = 0, cy = 0, cz = 0; int m = 0; bool fin = true;
                 for (int k = q * 4; k < q * 4 + 4 && k < ch.n; k++) {
-                    const float* cu = ops[kids[k0 + k]].cull;
+                    const float* cu = pass == 0 ? ops[kids[k0 + k]].cull : ops[kids[k0 + k]].cull_t;
                     fin = fin && std::isfinite(cu[3]);
                     cx += cu[0]; cy += cu[1]; cz += cu[2]; m++;
                 }
@@ -328,7 +371,7 @@ struct ListBuilder {
                     cx /= m; cy /= m; cz /= m;
                     double R = 0.0;
                     for (int k = q * 4; k < q * 4 + 4 && k < ch.n; k++) {
-                        const float* cu = ops[kids[k0 + k]].cull;
+                        const float* cu = pass == 0 ? ops[kids[k0 + k]].cull : ops[kids[k0 + k]].cull_t;
                         const double dx = cu[0] - cx, dy = cu[1] - cy, dz = cu[2] - cz;
                         R = std::fmax(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)cu[3]));
                     }
@@ -339,6 +382,7 @@ struct ListBuilder {
                 }
                 for (int k = 0; k < 4; k++) quad[(size_t)(first + c) * 32 + (q / 2) * 8 + k * 2 + (q & 1)] = s4[k];
             }
+            }
             if (nchunks > 1) ch.n |= (int32_t)CHUNK_TWO_LEVEL;
             chunks[first + c] = ch; counts[first + c] = cn;
         }
@@ -346,6 +390,7 @@ struct ListBuilder {
             const int li = build(g.second + 1, ops[g.second].skip);     // (no END op is emitted outside CSG)
             conts[g.first].list = li;
             static_assert(sizeof(ListChunk) == sizeof conts[0].child_hdr, "ContRec carries one ListChunk");
+            static_assert(sizeof(ContRec) == 256 && offsetof(ContRec, inv) == 128 && offsetof(ContRec, cull_loose) == 240, "the kernel reads ContRec by dword offsets");
             std::memcpy(conts[g.first].child_hdr, &chunks[li], sizeof(ListChunk));
         }
         return first;
@@ -353,7 +398,8 @@ struct ListBuilder {
     void finish() {
         while (lops.size() % 4) lops.push_back(-1);
         cull.resize((lops.size() / 4 + 3) * 16, INFINITY);              // whole quads + padding for the look-ahead loads
-        quad.resize(chunks.size() * 32, INFINITY);
+        cull_t.resize(cull.size(), INFINITY);
+        quad.resize(chunks.size() * 32, INFINITY); quad_t.resize(chunks.size() * 32, INFINITY);
         if (conts.empty()) { ContRec r; std::memset(&r, 0, sizeof r); conts.push_back(r); }
     }
 };
@@ -436,7 +482,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static void release_scene_memory(rtx_scene* s) {
     (void)hipSetDevice(s->device);
     for (void** p : {&s->d_ops, &s->d_bodies, &s->d_shapes, &s->d_paths, &s->d_materials, &s->d_lights, &s->d_pairs,
-                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts, &s->d_quad}) {
+                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts, &s->d_quad, &s->d_lcull_t, &s->d_quad_t}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -645,6 +691,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
         }
     if (prog.empty()) prog.resize(8, 0u);
     if ((rc = upload(ctx, lb.chunks, &s->d_chunks)) || (rc = upload(ctx, lb.counts, &s->d_counts)) || (rc = upload(ctx, lb.cull, &s->d_lcull)) || (rc = upload(ctx, lb.quad, &s->d_quad)) ||
+        (rc = upload(ctx, lb.cull_t, &s->d_lcull_t)) || (rc = upload(ctx, lb.quad_t, &s->d_quad_t)) ||
         (rc = upload(ctx, lb.lops, &s->d_lops)) || (rc = upload(ctx, lb.conts, &s->d_conts)) ||
         (rc = upload(ctx, prog, &s->d_pairs)) || (rc = upload(ctx, bodies, &s->d_bodies)) || (rc = upload(ctx, hits, &s->d_shapes)) ||
         (rc = upload(ctx, cc.paths, &s->d_paths)) || (rc = upload(ctx, mats, &s->d_materials)) ||
@@ -654,6 +701,7 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     }
     s->dev.bodies = (const OpBody*)s->d_bodies; s->dev.csg_prog = (const uint32_t*)s->d_pairs; s->dev.csg_prog_max = prog_max; s->dev.hits = (const HitRec*)s->d_shapes;
     s->dev.chunks = (const ListChunk*)s->d_chunks; s->dev.chunk_counts = (const ChunkCounts*)s->d_counts; s->dev.list_cull = (const float*)s->d_lcull; s->dev.quad_cull = (const float*)s->d_quad;
+    s->dev.list_cull_tight = (const float*)s->d_lcull_t; s->dev.quad_cull_tight = (const float*)s->d_quad_t;
     s->dev.list_ops = (const int32_t*)s->d_lops; s->dev.cont_recs = (const ContRec*)s->d_conts;
     s->dev.path_ops = (const int32_t*)s->d_paths; s->dev.materials = (const MaterialRec*)s->d_materials;
     s->dev.lights = (const LightRec*)s->d_lights;

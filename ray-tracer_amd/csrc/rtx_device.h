@@ -85,7 +85,7 @@ struct ListChunk {           // 32 bytes = one s_load_dwordx8
 #define CHUNK_TWO_LEVEL 0x100u
 struct __attribute__((aligned(128))) ContRec {   // 256 bytes; the kernel reads the first half with one batch of scalar loads
     // ---- first half (128 bytes): all a visit needs unless the transform is XF_GENERAL
-    float cull[4];           // bounding sphere in parent space (same as the sweep's)
+    float cull[4];           // bounding sphere in parent space (same as the sweep's: the tight one, see list_cull_tight)
     int32_t list;            // groups: first chunk of the child list; CSG roots: offset of the program in csg_prog (dwords)
     int32_t flags;           // CONT_* | XF_* << CONT_XF_SHIFT
     double t[3];             // translation column of the inverse (XF_TRANSLATE: origin = p + t); CSG roots: the first
@@ -97,7 +97,7 @@ struct __attribute__((aligned(128))) ContRec {   // 256 bytes; the kernel reads 
     double w33;
     int32_t op;              // the container's BEGIN op      (host side)
     int32_t skip;            // op index past the container    (host side)
-    uint32_t pad1[4];
+    float cull_loose[4];     // the sphere around the container's bounds (read in the reference-faithful counting mode only)
 };
 enum { CONT_DIV = 1, CONT_NOFILTER = 2, CONT_CSG = 4, CONT_XF_SHIFT = 4 };
 #define CONT_XF(f) (((f) >> CONT_XF_SHIFT) & 3)
@@ -140,6 +140,8 @@ struct SceneDev {
     const ChunkCounts* chunk_counts;
     const float* list_cull;   // quads of bounding spheres in list order: {cxA,cxB,cyA,cyB,czA,czB,r2A,r2B} x 2 per 4 children
     const float* quad_cull;   // per chunk: the bounding spheres of its eight quads of children, 2 x 16 floats in the pair layout
+    const float* list_cull_tight;   // list_cull / quad_cull with the tighter spheres of CSG roots (rtx_api.hip: extent_sphere); the
+    const float* quad_cull_tight;   //   kernel sweeps these unless reference-faithful node-visit counts are asked for
     const int32_t* list_ops;  // op index per child slot
     const ContRec* cont_recs;
     const uint32_t* csg_prog; // the programs of all CSG roots (CSGP_* records below), walked from LDS by the kernel

@@ -783,7 +783,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         {
             const AS4 ListChunk* chunks = (const AS4 ListChunk*)(uintptr_t)sc.chunks;
             const AS4 ContRec* conts = (const AS4 ContRec*)(uintptr_t)sc.cont_recs;
-            const AS4 F16* lq = (const AS4 F16*)(uintptr_t)sc.list_cull;
+            // (the spheres of CSG roots are the tight ones unless the reference's node-visit counts are to be reproduced: a lane that
+            // misses the tight sphere gets an empty list from the CSG, but the reference would still have visited its children)
+            const AS4 F16* lq = (const AS4 F16*)(uintptr_t)(rp.no_early_out ? sc.list_cull : sc.list_cull_tight);
             const AS4 int32_t* lops = (const AS4 int32_t*)(uintptr_t)sc.list_ops;
             int level = 0, chunk = 0;
             unsigned U = 0;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             // (two loads); only the quads SOME lane's ray may touch are swept, two per wait.  A coherent wave —
                             // primary rays of one tile, their shadow rays — touches one or two quads of a chunk.
                             const int q0 = child_base >> 2, nq = (n + 3) >> 2;
-                            const AS4 F16* sq = (const AS4 F16*)(uintptr_t)sc.quad_cull + 2 * chunk;
+                            const AS4 F16* sq = (const AS4 F16*)(uintptr_t)(rp.no_early_out ? sc.quad_cull : sc.quad_cull_tight) + 2 * chunk;
                             F16 sa = sq[0];
                             const AS4 F16* psb = sq + 1;
                             asm volatile("" : "+s"(psb));
@@ -960,6 +962,11 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         sync_level(level);
                         Head ch = {};
                         ch[4] = ra[0]; ch[5] = ra[1]; ch[6] = ra[2]; ch[7] = ra[3];
+                        if (rp.no_early_out) {                       // counting mode: the sphere around the bounds
+                            typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+                            const U4 lc = *(const AS4 U4*)((const AS4 uint32_t*)crp + 60);
+                            ch[4] = lc[0]; ch[5] = lc[1]; ch[6] = lc[2]; ch[7] = lc[3];
+                        }
                         return cull_miss(ch, fox, foy, foz, fdx, fdy, fdz, fdd, (!sc.has_transparency && !rp.no_early_out) ? 0.f : -__builtin_inff());
                     };
                     if (CSG && (cflags & CONT_CSG)) {
