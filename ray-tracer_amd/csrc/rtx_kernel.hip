@@ -698,11 +698,90 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     }
                 }
                 TMI(tm_body);
-            } else if (active) {
+            } else {
+                // ================= CSG_MID / CSG_END / GROUP_END: list work of the lanes that are in
                 const int sh = OPH_CLEVEL(info) * 8;
                 if (kind == OPK_CSG_MID) {
-                    mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
+                    if (active) mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
                 } else {
+                    // The merge / filter of csg.rs:83-121 on the lanes' LDS lists is a chain of ~60 dependent LDS round trips
+                    // per END op when done in place.  FAST PATH: segments of at most four entries (two children with two hits
+                    // each: the common case) are read into registers at once, marked, sorted, filtered and handed on there.
+                    // It is taken when EVERY participating lane's segment is that short and no lane has two equal t after
+                    // the sort (the reference re-inserts survivors by binary search, intersections.rs:41-47, whose result
+                    // differs from appending only among equal keys); otherwise all lanes take the in-place code below.
+                    const int s0w = (int)((starts >> sh) & 0xff);
+                    const int lenw = cnt - s0w;
+                    bool fast = !__any(active && lenw > 4);
+                    double ft0 = INF, ft1 = INF, ft2 = INF, ft3 = INF; uint32_t fi0 = 0, fi1 = 0, fi2 = 0, fi3 = 0;
+                    if (fast) {
+                        if (active) {
+                            if (lenw > 0) { ft0 = lt(s0w); fi0 = ls(s0w); }
+                            if (lenw > 1) { ft1 = lt(s0w + 1); fi1 = ls(s0w + 1); }
+                            if (lenw > 2) { ft2 = lt(s0w + 2); fi2 = ls(s0w + 2); }
+                            if (lenw > 3) { ft3 = lt(s0w + 3); fi3 = ls(s0w + 3); }
+                            if (kind == OPK_CSG_END) {
+                                // csg.rs:83-90: left_shapes membership == "came from the left child"
+                                const int ml = (int)((mids >> sh) & 0xff) - s0w;      // entries of the left child
+                                fi0 = 0 < ml ? (fi0 | LBIT) : (fi0 & ~LBIT); fi1 = 1 < ml ? (fi1 | LBIT) : (fi1 & ~LBIT);
+                                fi2 = 2 < ml ? (fi2 | LBIT) : (fi2 & ~LBIT); fi3 = 3 < ml ? (fi3 | LBIT) : (fi3 & ~LBIT);
+                            }
+                            // stable sort (intersections.rs:56-59): insertion sort as adjacent exchanges on strict >, the
+                            // comparisons the in-place loop makes (absent entries hold +inf and stay behind)
+#define FSWAP(a, b) do { const bool sw_ = ft##a > ft##b; const double tt_ = sw_ ? ft##b : ft##a; ft##b = sw_ ? ft##a : ft##b; ft##a = tt_; \
+                         const uint32_t ii_ = sw_ ? fi##b : fi##a; fi##b = sw_ ? fi##a : fi##b; fi##a = ii_; } while (0)
+                            FSWAP(0, 1); FSWAP(1, 2); FSWAP(0, 1); FSWAP(2, 3); FSWAP(1, 2); FSWAP(0, 1);
+#undef FSWAP
+                        }
+                        const bool tie = active && kind == OPK_CSG_END &&
+                                         ((lenw > 1 && ft0 == ft1) || (lenw > 2 && ft1 == ft2) || (lenw > 3 && ft2 == ft3));
+                        if (__any(tie)) fast = false;
+                    }
+                    if (fast) {
+                        if (active) {
+                            int n_out = lenw;
+                            if (kind == OPK_CSG_END) {
+                                // filter_intersections (csg.rs:94-121); keys are distinct here, so re-insertion = appending
+                                const int cop = aux;
+                                bool inl = false, inr = false;
+                                double o0 = INF, o1 = INF, o2 = INF, o3 = INF; uint32_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+                                n_out = 0;
+#define FSTEP(k) do { if (lenw > k) { EV(RTX_EV_CSG_ENTRIES, 1); const bool lhit = (fi##k & LBIT) != 0; bool allowed; \
+                          if (cop == RTX_CSG_UNION) allowed = (lhit && !inr) || (!lhit && !inl); \
+                          else if (cop == RTX_CSG_INTERSECTION) allowed = (lhit && inr) || (!lhit && inl); \
+                          else allowed = (lhit && !inr) || (!lhit && inl); \
+                          if (allowed) { \
+                              o0 = n_out == 0 ? ft##k : o0; j0 = n_out == 0 ? fi##k : j0; o1 = n_out == 1 ? ft##k : o1; j1 = n_out == 1 ? fi##k : j1; \
+                              o2 = n_out == 2 ? ft##k : o2; j2 = n_out == 2 ? fi##k : j2; o3 = n_out == 3 ? ft##k : o3; j3 = n_out == 3 ? fi##k : j3; \
+                              n_out++; } \
+                          if (lhit) inl = !inl; else inr = !inr; } } while (0)
+                                FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3);
+#undef FSTEP
+                                ft0 = o0; ft1 = o1; ft2 = o2; ft3 = o3; fi0 = j0; fi1 = j1; fi2 = j2; fi3 = j3;
+                            }
+                            cnt = s0w + n_out;
+                            if (kind == OPK_CSG_END && (flags & OPF_ROOT)) {
+                                // hand the filtered list of this CSG root to the running state (entries ascending in t)
+                                const int h0 = (int)(fi0 & ~LBIT), h1 = (int)(fi1 & ~LBIT), h2 = (int)(fi2 & ~LBIT), h3 = (int)(fi3 & ~LBIT);
+                                const bool g0 = n_out > 0 && !(ft0 >= 0.0), g1 = n_out > 1 && !(ft1 >= 0.0), g2 = n_out > 2 && !(ft2 >= 0.0), g3 = n_out > 3 && !(ft3 >= 0.0);
+                                bool open = true;      // no entry with t >= 0 met yet
+#define FHAND(k) do { if (open && n_out > k) { const int shape = h##k; \
+                          const int negs = (g0 && h0 == shape) + (g1 && h1 == shape) + (g2 && h2 == shape) + (g3 && h3 == shape); \
+                          if (ft##k >= 0.0) { if (closer(ft##k, shape)) { best_t = ft##k; best_op = shape; best_inside = (negs == 1); } open = false; } \
+                          else if (negs == 1) enter(ft##k, shape); } } while (0)
+                                FHAND(0); FHAND(1); FHAND(2); FHAND(3);
+#undef FHAND
+                                cnt = 0;
+                                if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = 0x7fffffff; decided = true; }
+                            } else {
+                                // the merged (and filtered) segment goes back for the enclosing CSG
+                                if (n_out > 0) { lt(s0w) = ft0; ls(s0w) = fi0; }
+                                if (n_out > 1) { lt(s0w + 1) = ft1; ls(s0w + 1) = fi1; }
+                                if (n_out > 2) { lt(s0w + 2) = ft2; ls(s0w + 2) = fi2; }
+                                if (n_out > 3) { lt(s0w + 3) = ft3; ls(s0w + 3) = fi3; }
+                            }
+                        }
+                    } else if (active) {
                     const int s0 = (int)((starts >> sh) & 0xff);
                     if (kind == OPK_CSG_END) {
                         // csg.rs:83-90: left_shapes membership == "came from the left child"
@@ -765,6 +844,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             cnt = 0;
                             if (is_shadow && !rp.no_early_out && best_op >= 0 && best_t < shadow_dist) { resume_at = 0x7fffffff; decided = true; }
                         }
+                    }
                     }
                 }
             }
