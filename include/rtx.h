@@ -205,6 +205,10 @@ typedef struct rtx_comm rtx_comm;
 int  rtx_comm_unique_id(void* id /* RTX_COMM_ID_BYTES */);
 int  rtx_comm_init_rank(rtx_ctx*, const void* id, int rank, int world_size, rtx_comm** out);
 int  rtx_comm_init_all(rtx_ctx* const* ctxs, int n, rtx_comm** out /* n handles */);
+/* No counterpart in the reference and no RCCL: a communicator whose `world_size` ranks are all THIS GPU.  Every
+ * rtx_render_gathered renders the N band sets one after the other where the all-gather would have put them and runs the
+ * same de-interleave.  For checking the band mapping of N > 1 on a single GPU (tests), not for speed. */
+int  rtx_comm_init_loopback(rtx_ctx*, int world_size, rtx_comm** out);
 void rtx_comm_destroy(rtx_comm*);
 int  rtx_comm_rank(const rtx_comm*);
 int  rtx_comm_size(const rtx_comm*);

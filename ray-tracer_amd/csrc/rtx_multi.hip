@@ -77,6 +77,7 @@ struct rtx_comm {
     rtx_ctx* ctx = nullptr;
     int rank = 0, world = 1;
     ncclComm_t nccl = nullptr;
+    bool loopback = false;                       // all `world` ranks are this GPU, no RCCL (rtx_comm_init_loopback)
     hipStream_t gstream = nullptr;               // the gather runs here, beside the next frame's render
     // two buffer sets: frame k renders into set k & 1 while frame k - 1's set is still being gathered
     uint8_t* d_band[2] = {nullptr, nullptr}; uint8_t* d_all[2] = {nullptr, nullptr}; size_t band_cap = 0;
@@ -153,9 +154,28 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
     if (rc != RTX_OK) return rc;
     const int b = (int)(c->seq & 1u);
     if (c->used[b]) HIPCHK(ctx, hipStreamWaitEvent(st, c->ev_gather[b], 0));      // the set's previous gather has read it
-    rc = rtx_render_device(ctx, scene, cam, max_depth, rtx_bands{c->rank, c->world}, flags | RTX_F_BANDS_COMPACT,
-                           c->d_band[b], want_hit ? c->d_band_hit[b] : nullptr, st, stats);
-    if (rc != RTX_OK) return rc;
+    if (c->loopback) {
+        // every rank's share in turn, each where the all-gather would have put it
+        const size_t band_px = (size_t)rows_padded(cam->vsize, c->world) * cam->hsize;
+        rtx_stats sum{}, one{};
+        for (int r = 0; r < c->world; r++) {
+            rc = rtx_render_device(ctx, scene, cam, max_depth, rtx_bands{r, c->world}, flags | RTX_F_BANDS_COMPACT,
+                                   c->d_all[b] + (size_t)r * band_px * 3, want_hit ? c->d_all_hit[b] + (size_t)r * band_px : nullptr,
+                                   st, stats ? &one : nullptr);
+            if (rc != RTX_OK) return rc;
+            if (stats) {
+                sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
+                for (int k = 0; k < RTX_EV_COUNT; k++) sum.ev[k] += one.ev[k];
+                sum.overflow_pixels += one.overflow_pixels; sum.rays_shadow_skipped += one.rays_shadow_skipped;
+                sum.kernel_ms += one.kernel_ms;
+            }
+        }
+        if (stats) *stats = sum;
+    } else {
+        rc = rtx_render_device(ctx, scene, cam, max_depth, rtx_bands{c->rank, c->world}, flags | RTX_F_BANDS_COMPACT,
+                               c->d_band[b], want_hit ? c->d_band_hit[b] : nullptr, st, stats);
+        if (rc != RTX_OK) return rc;
+    }
     HIPCHK(ctx, hipEventRecord(c->ev_render[b], st));
     c->cur = b; c->W = cam->hsize; c->H = cam->vsize; c->want_hit = want_hit;
     return RTX_OK;
@@ -168,6 +188,7 @@ int comm_all_gather(rtx_comm* c) {
     const size_t band_px = (size_t)rows_padded(c->H, c->world) * c->W;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamWaitEvent(c->gstream, c->ev_render[b], 0));
+    if (c->loopback) return RTX_OK;              // the shares were rendered into place
     NCCLCHK(ctx, rccl()->AllGather(c->d_band[b], c->d_all[b], band_px * 3, ncclUint8, c->nccl, c->gstream));
     if (c->want_hit) NCCLCHK(ctx, rccl()->AllGather(c->d_band_hit[b], c->d_all_hit[b], band_px, ncclInt32, c->nccl, c->gstream));
     return RTX_OK;
@@ -258,6 +279,17 @@ int rtx_comm_init_all(rtx_ctx* const* ctxs, int n, rtx_comm** out) {
     }
     if (rc != RTX_OK) for (int i = 0; i < n; i++) { rtx_comm_destroy(out[i]); out[i] = nullptr; }
     return rc;
+}
+
+int rtx_comm_init_loopback(rtx_ctx* ctx, int world_size, rtx_comm** out) {
+    if (!ctx || !out || world_size < 1) return RTX_E_INVALID;
+    *out = nullptr;
+    rtx_comm* c = new rtx_comm();
+    c->ctx = ctx; c->rank = 0; c->world = world_size; c->loopback = true;
+    int rc = comm_finish_init(c);
+    if (rc != RTX_OK) { rtx_comm_destroy(c); return rc; }
+    *out = c;
+    return RTX_OK;
 }
 
 void rtx_comm_destroy(rtx_comm* c) {

@@ -549,6 +549,43 @@ def test_render_device_writes_device_buffers_on_the_callers_stream(ctx):
         hip.lib.hipStreamDestroy(st)
 
 
+def test_band_shares_of_2_3_8_ranks_assemble_to_the_full_frame_on_the_device(ctx):
+    """The N > 1 data path without RCCL: a loopback communicator (rtx_comm_init_loopback) renders the compact band sets of
+    all N ranks on this one GPU, each where the all-gather would have delivered it, and the product's de-interleave kernel
+    assembles the frame.  Must equal rtx_render byte for byte (ids and ray counts too), for ragged heights (last band
+    partial, ranks with unequal numbers of bands, more ranks than bands) and row lengths that are and are not multiples of 16 bytes."""
+    import rtx
+    hip = _Hip()
+    bufs = []
+    try:
+        for name, w, h in (("S4", 333, 171), ("S5", 320, 180), ("S1", 64, 9), ("S2", 128, 70)):
+            pw, pc = rtx.load_yaml(parity.scene_text(name, w, h))
+            sc = ctx.scene(pw)
+            try:
+                want = sc.render(pc[0], 5)
+                for n in (2, 3, 8):
+                    comm = rtx.Comm.loopback(ctx, n)
+                    try:
+                        assert rtx.LIB.rtx_comm_size(comm.h) == n
+                        for rep in range(2):                        # both internal buffer sets
+                            frame = hip.malloc(h * w * 3, 0x33); ids = hip.malloc(h * w * 4, 0x44)
+                            bufs += [frame, ids]
+                            stats = comm.render_gathered(sc, pc[0], frame.value, ids.value, 5, stats=(rep == 0))
+                            comm.wait()
+                            assert np.array_equal(hip.to_host(frame, h * w * 3, np.uint8).reshape(h, w, 3), want["rgb"]), (name, n)
+                            assert np.array_equal(hip.to_host(ids, h * w * 4, np.int32).reshape(h, w), want["hit"]), (name, n)
+                            if stats is not None:
+                                assert (stats.rays_primary, stats.rays_shadow, stats.rays_secondary) == \
+                                       (want["stats"].rays_primary, want["stats"].rays_shadow, want["stats"].rays_secondary), (name, n)
+                    finally:
+                        comm.close()
+            finally:
+                sc.close()
+    finally:
+        for b in bufs:
+            hip.lib.hipFree(b)
+
+
 def test_multi_gpu_entry_points_with_a_one_rank_communicator(ctx, tmp_path):
     """The C-ABI multi-GPU render (rtx_comm_* / rtx_render_gathered / rtx_render_multi, `rtx --gpus N`): bands of rank r of N,
     ONE ncclAllGather (RCCL, opened by the library itself), de-interleave kernel.  The box has one GPU, so the communicator
