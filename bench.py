@@ -113,6 +113,12 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py start them: "
                          "run it without a torch.distributed environment)" % (args.gpus, world_size))
 
+    # ONE JSON line on stdout: libraries below print banners of their own through C stdio (RCCL's version block at the
+    # first communicator), so file descriptor 1 is pointed at stderr for the run and the line goes to the saved one
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import flops
     import rtx
@@ -128,7 +134,12 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     N = world_size
     dist = None
-    if N > 1:
+    # rehearsal of the communicator path on one GPU: RTX_BENCH_FORCE_COMM=1 runs N = 1 through torch.distributed (nccl, one
+    # rank) and rtx_render_gathered exactly as N > 1 does.  The driver's runs never set it.
+    force_comm = N == 1 and os.environ.get("RTX_BENCH_FORCE_COMM") == "1"
+    if force_comm:
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if N > 1 or force_comm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -156,7 +167,7 @@ def main():
     # the product's communicator for the band gather (RCCL inside librtx_hip.so); torch.distributed only carries the 128-byte id,
     # the barrier and the max-over-ranks of the timings
     comm = None
-    if N > 1 and backend == "nccl":
+    if (N > 1 or force_comm) and backend == "nccl":
         idt = torch.zeros(rtx.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(rtx.comm_unique_id()), dtype=torch.uint8))
@@ -174,7 +185,7 @@ def main():
         bands = (rank, N)
         rows_pad = rtx.LIB.rtx_band_rows_padded(height, N)
         local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
-        frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=dev) for _ in range(2)] if N > 1 else None
+        frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=dev) for _ in range(4)] if (N > 1 or comm is not None) else None
         gathered_host = torch.zeros((N, rows_pad * width * 3), dtype=torch.uint8) if (N > 1 and comm is None) else None
 
         # exact ray and event counts of this rank's share (untimed); a device-side overflow would raise here.  Two passes:
@@ -198,7 +209,7 @@ def main():
 
         def step(k):
             if comm is not None:
-                comm.render_gathered(scene, cam, frames[k & 1].data_ptr(), 0, 5, 0, stream)
+                comm.render_gathered(scene, cam, frames[k & 3].data_ptr(), 0, 5, 0, stream)
             else:
                 scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
                 if N > 1:      # gloo rehearsal: host gather + the C ABI's host de-interleave
@@ -217,10 +228,10 @@ def main():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         for k in range(steps):
-            if N == 1:
+            if comm is None and N == 1:
                 ev[k][0].record()
             step(k)
-            if N == 1:
+            if comm is None and N == 1:
                 ev[k][1].record()
         if comm is not None:
             comm.wait()                               # host waits for the last gather + de-interleave (and polls the sticky error)
@@ -229,11 +240,11 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         ctx.poll(wait=True)                           # an overflow in any timed frame is an error, not a number
-        if N == 1:
+        if comm is None and N == 1:
             kern = sum(a.elapsed_time(b) for a, b in ev) / steps
         else:
             # per-rank kernel time of its share, from the library's own HIP events (3 synchronous renders after the timed region:
-            # inside it the render of frame k+1 overlaps the gather of frame k on another stream)
+            # inside it consecutive frames run on alternating render lanes and overlap each other and the gathers)
             kern = min(scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, True).kernel_ms for _ in range(3))
         t = torch.tensor([t1 - t0, kern], dtype=torch.float64, device=dev)
         if N > 1:
@@ -271,7 +282,7 @@ def main():
     out = None
     if rank == 0:
         gather = ("row-interleaved 8-row bands x%d + one ncclAllGather per frame inside the product (rtx_render_gathered), "
-                  "overlapped with the next frame's render" % N) if comm is not None else \
+                  "two frames in flight on alternating render lanes" % N) if comm is not None else \
                  ("row-interleaved 8-row bands x%d, gloo REHEARSAL gather through host memory" % N if N > 1 else "1 GPU")
         m["roofline"]["note"] = ("achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events (counted by a "
                                  "pass in the reference-faithful mode: is_shadowed visits everything, as world.rs:196-206 does) x the survey's "
@@ -299,7 +310,8 @@ def main():
     if rank == 0:
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["text"], m["width"], m["height"])
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if comm is not None:
         comm.close()
     ctx.close()

@@ -212,12 +212,19 @@ int  rtx_comm_init_loopback(rtx_ctx*, int world_size, rtx_comm** out);
 void rtx_comm_destroy(rtx_comm*);
 int  rtx_comm_rank(const rtx_comm*);
 int  rtx_comm_size(const rtx_comm*);
+/* Diagnostic: how many of the communicator's streams (render lanes + gather stream) were found to run side by side on this
+ * machine's hardware queues when it was created (wanted: frames in flight + 1; 1 = everything serialises). */
+int  rtx_comm_concurrency(const rtx_comm*);
 
-/* Camera::render (camera.rs:39-54) on all ranks of `comm`: queues this rank's bands on `stream` (NULL = the context's),
- * then the all-gather and the de-interleave on the communicator's own stream, so the next frame's render overlaps this
- * frame's gather (two internal buffer sets).  d_frame: hsize*vsize*3 device bytes, row-major, complete on EVERY rank;
- * d_hit_frame: NULL or hsize*vsize int32.  Returns once everything is queued; the frame is ready after rtx_comm_wait.
- * stats != NULL waits for this rank's render and returns ITS share's counts.  scene must belong to comm's context. */
+/* Camera::render (camera.rs:39-54) on all ranks of `comm`: queues this rank's bands, then the all-gather and the
+ * de-interleave on the communicator's own stream.  Consecutive calls render on alternating internal render lanes (two
+ * frames in flight by default; option "pipeline" / RTX_PIPELINE = 1..4, read when the communicator is created), each
+ * behind the work `stream` (NULL = the context's) holds at the time of the call: the start of frame k+1 fills the wave
+ * slots the tail of frame k leaves idle, and its render overlaps frame k's gather.  Later work on `stream` does NOT wait
+ * for the frame: rtx_comm_wait does.  d_frame: hsize*vsize*3 device bytes, row-major, complete on EVERY rank (a buffer
+ * per frame in flight); d_hit_frame: NULL or hsize*vsize int32.  Returns once everything is queued.
+ * stats != NULL renders on `stream` itself, waits for this rank's render and returns ITS share's counts.  scene must
+ * belong to comm's context. */
 int  rtx_render_gathered(rtx_comm*, const rtx_scene*, const rtx_camera*, int max_depth, uint32_t flags,
                          void* d_frame, void* d_hit_frame, void* stream, rtx_stats* stats);
 /* Makes `stream` wait (on the device) for the last rtx_render_gathered's frame; stream == NULL: the HOST waits, and the

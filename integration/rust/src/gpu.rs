@@ -118,6 +118,7 @@ extern "C" {
     pub fn rtx_comm_init_rank(ctx: *mut RtxCtx, id: *const std::ffi::c_void, rank: i32, world_size: i32,
                               out: *mut *mut RtxComm) -> i32;
     pub fn rtx_comm_init_all(ctxs: *const *mut RtxCtx, n: i32, out: *mut *mut RtxComm) -> i32;
+    pub fn rtx_comm_concurrency(comm: *const RtxComm) -> i32;
     pub fn rtx_comm_init_loopback(ctx: *mut RtxCtx, world_size: i32, out: *mut *mut RtxComm) -> i32;
     pub fn rtx_comm_destroy(comm: *mut RtxComm);
     pub fn rtx_render_gathered(comm: *mut RtxComm, scene: *const RtxScene, cam: *const RtxCamera, max_depth: i32,

@@ -502,6 +502,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.split = env_int("RTX_SPLIT", -1);
     c->opt.split_class = env_int("RTX_SPLIT_CLASS", 6);
     c->opt.debug = env_int("RTX_DEBUG", 0);
+    c->opt.pipeline = env_int("RTX_PIPELINE", 2);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -574,6 +575,7 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "split") c->opt.split = value;
     else if (n == "split_class") c->opt.split_class = value;
     else if (n == "debug") c->opt.debug = value;
+    else if (n == "pipeline") c->opt.pipeline = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
 }
@@ -754,7 +756,7 @@ int rtx_band_rows(int vsize, rtx_bands b) {
 
 namespace {
 
-constexpr size_t kCounterWords = (size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE;
+constexpr size_t kCounterWords = RTX_COUNTER_WORDS;
 
 // Queues one render (counter reset, optional tile-order probe, frame launch) on `st`; nothing here waits.
 int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,

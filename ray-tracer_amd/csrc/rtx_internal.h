@@ -18,7 +18,11 @@ struct rtx_opts {
     int split = -1;          // split tiles: -1 = default (short dispatches), 0 / 1 = forced
     int split_class = 6;     // tiles of this cost class and above are split
     int debug = 0;
+    int pipeline = 2;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
+                             // 2..4; below 2 = every frame on the caller's stream)
 };
+
+constexpr size_t RTX_COUNTER_WORDS = (size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE;   // one replicated counter block
 
 struct rtx_scene;
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,11 +80,18 @@ struct rtx_comm {
     ncclComm_t nccl = nullptr;
     bool loopback = false;                       // all `world` ranks are this GPU, no RCCL (rtx_comm_init_loopback)
     hipStream_t gstream = nullptr;               // the gather runs here, beside the next frame's render
-    // two buffer sets: frame k renders into set k & 1 while frame k - 1's set is still being gathered
-    uint8_t* d_band[2] = {nullptr, nullptr}; uint8_t* d_all[2] = {nullptr, nullptr}; size_t band_cap = 0;
-    int32_t* d_band_hit[2] = {nullptr, nullptr}; int32_t* d_all_hit[2] = {nullptr, nullptr}; size_t hit_cap = 0;
-    hipEvent_t ev_render[2] = {nullptr, nullptr}, ev_gather[2] = {nullptr, nullptr};
-    bool used[2] = {false, false};
+    // n_sets buffer sets (2..kSets): frame k renders into set k % n_sets while the sets of the frames before it are still
+    // being rendered / gathered
+    static constexpr int kSets = 4;
+    int n_sets = 2;
+    int n_concurrent = 1;                        // mutually concurrent streams found (lanes + gather stream)
+    uint8_t* d_band[kSets] = {}; uint8_t* d_all[kSets] = {}; size_t band_cap = 0;
+    int32_t* d_band_hit[kSets] = {}; int32_t* d_all_hit[kSets] = {}; size_t hit_cap = 0;
+    hipEvent_t ev_render[kSets] = {}, ev_gather[kSets] = {};
+    // one render lane per set (stream, side stream, tile lists, counters): frame k renders on lane k % n_sets, so the START of frame
+    // k + 1 (its probe launch, its expensive tiles) fills the wave slots that the TAIL of frame k leaves empty
+    rtx_ctx::Lane lane[kSets]; unsigned long long* d_counters[kSets] = {}; hipEvent_t ev_call[kSets] = {};
+    bool used[kSets] = {};
     unsigned seq = 0;
     // what the last rtx_comm_render_bands queued, for the gather step
     int cur = 0; int W = 0, H = 0; bool want_hit = false;
@@ -96,13 +104,93 @@ int nccl_fail(rtx_ctx* ctx, const char* what, ncclResult_t r) {
 }
 #define NCCLCHK(ctx, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return nccl_fail(ctx, #call, r_); } while (0)
 
+// ---- which streams really run side by side (see comm_finish_init)
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();                 // 100 MHz constant clock: the loop ends whatever happens
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// wall time of one 100 us spin on each of the given streams, started together; ~100 us if they overlap
+double spin_together(const std::vector<hipStream_t>& ss, bool* ok) {
+    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) *ok = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (hipStream_t s : ss) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, 10000ull);
+    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) *ok = false;
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+bool overlap(rtx_ctx*, hipStream_t a, hipStream_t b) {
+    bool ok = true;
+    double best = 1e30;
+    for (int k = 0; k < 2; k++) { const double t = spin_together({a, b}, &ok); if (t < best) best = t; }
+    return ok && best < 160.0;
+}
+
+// greedy: keep a candidate if it overlaps with everything kept so far
+int pick_streams(rtx_ctx* ctx, const std::vector<hipStream_t>& pool, int want, std::vector<hipStream_t>* chosen) {
+    bool ok = true;
+    (void)spin_together({pool[0]}, &ok);                            // warm-up: code object load
+    chosen->assign(1, pool[0]);
+    for (size_t i = 1; i < pool.size() && (int)chosen->size() < want; i++) {
+        std::vector<hipStream_t> trial = *chosen; trial.push_back(pool[i]);
+        double best = 1e30;
+        for (int k = 0; k < 2; k++) { const double t = spin_together(trial, &ok); if (t < best) best = t; }
+        if (best < 160.0) chosen->push_back(pool[i]);
+    }
+    if (!ok) return rtx_fail(ctx, RTX_E_DEVICE, "stream calibration failed");
+    return RTX_OK;
+}
+
 int comm_finish_init(rtx_comm* c) {
     rtx_ctx* ctx = c->ctx;
+    c->n_sets = ctx->opt.pipeline < 2 ? 2 : (ctx->opt.pipeline > rtx_comm::kSets ? rtx_comm::kSets : ctx->opt.pipeline);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
+    // HIP deals its few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) to streams by a policy of its own, and launches
+    // on streams that share a hardware queue run one after the other.  The frames in flight must really overlap, so
+    // the streams are PICKED: from a pool of candidates, by running two short timed spin kernels side by side
+    // (pick_streams: ~1 ms per communicator).  Wanted: the lane streams and the gather stream mutually concurrent; the
+    // side stream of a lane (SPLIT launch) concurrent with its own lane at least.
+    {
+        std::vector<hipStream_t> pool(2 * rtx_comm::kSets + 2, nullptr);
+        for (hipStream_t& p : pool) HIPCHK(ctx, hipStreamCreateWithFlags(&p, hipStreamNonBlocking));
+        std::vector<hipStream_t> chosen;
+        int rc = pick_streams(ctx, pool, c->n_sets + 1, &chosen);
+        if (rc != RTX_OK) { for (hipStream_t p : pool) if (p) (void)hipStreamDestroy(p); return rc; }
+        // the mutually concurrent streams first (at least one was found), then the others: lanes, gather stream, and
+        // what is left over as candidates for the side streams
+        c->n_concurrent = (int)chosen.size();
+        auto taken = [&](hipStream_t p) { for (hipStream_t q : chosen) if (q == p) return true; return false; };
+        std::vector<hipStream_t> order = chosen;
+        for (hipStream_t p : pool) if (!taken(p)) order.push_back(p);
+        for (int b = 0; b < c->n_sets; b++) c->lane[b].stream = order[b];
+        c->gstream = order[c->n_sets];
+        std::vector<hipStream_t> rest(order.begin() + c->n_sets + 1, order.end());
+        for (int b = 0; b < c->n_sets; b++) {
+            // a leftover stream that runs beside ALL the chosen ones (a hardware queue of its own) if there is one, else
+            // one that runs beside this lane's own stream at least
+            size_t best = rest.size();
+            for (size_t i = 0; i < rest.size() && best == rest.size(); i++) {
+                if (!rest[i]) continue;
+                std::vector<hipStream_t> trial = chosen; trial.push_back(rest[i]);
+                bool ok = true; double t = spin_together(trial, &ok); const double t2 = spin_together(trial, &ok); if (t2 < t) t = t2;
+                if (ok && t < 160.0) best = i;
+            }
+            for (size_t i = 0; i < rest.size() && best == rest.size(); i++)
+                if (rest[i] && overlap(ctx, c->lane[b].stream, rest[i])) best = i;
+            for (size_t i = 0; i < rest.size() && best == rest.size(); i++) if (rest[i]) best = i;
+            c->lane[b].side = rest[best]; rest[best] = nullptr;
+        }
+        for (hipStream_t p : rest) if (p) (void)hipStreamDestroy(p);
+    }
+    for (int b = 0; b < c->n_sets; b++) {
         HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_render[b], hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_gather[b], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_call[b], hipEventDisableTiming));
+        rtx_ctx::Lane& ln = c->lane[b];
+        HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+        HIPCHK(ctx, hipMalloc((void**)&ln.d_tile_counts, 64 * sizeof(int32_t)));
+        HIPCHK(ctx, hipMalloc((void**)&c->d_counters[b], RTX_COUNTER_WORDS * sizeof(unsigned long long)));
     }
     return RTX_OK;
 }
@@ -112,13 +200,13 @@ int comm_reserve(rtx_comm* c, int W, int H, bool want_hit) {
     const size_t band_px = (size_t)rows_padded(H, c->world) * W;
     if (band_px * 3 > c->band_cap) {
         HIPCHK(ctx, hipStreamSynchronize(c->gstream));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < c->n_sets; b++) {
             if (c->d_band[b]) (void)hipFree(c->d_band[b]);
             if (c->d_all[b]) (void)hipFree(c->d_all[b]);
             c->d_band[b] = c->d_all[b] = nullptr;
         }
         c->band_cap = 0;
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < c->n_sets; b++) {
             HIPCHK(ctx, hipMalloc((void**)&c->d_band[b], band_px * 3));
             HIPCHK(ctx, hipMalloc((void**)&c->d_all[b], band_px * 3 * c->world));
             HIPCHK(ctx, hipMemset(c->d_band[b], 0, band_px * 3));              // (the padding rows of the last band are sent too)
@@ -127,13 +215,13 @@ int comm_reserve(rtx_comm* c, int W, int H, bool want_hit) {
     }
     if (want_hit && band_px * 4 > c->hit_cap) {
         HIPCHK(ctx, hipStreamSynchronize(c->gstream));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < c->n_sets; b++) {
             if (c->d_band_hit[b]) (void)hipFree(c->d_band_hit[b]);
             if (c->d_all_hit[b]) (void)hipFree(c->d_all_hit[b]);
             c->d_band_hit[b] = c->d_all_hit[b] = nullptr;
         }
         c->hit_cap = 0;
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < c->n_sets; b++) {
             HIPCHK(ctx, hipMalloc((void**)&c->d_band_hit[b], band_px * 4));
             HIPCHK(ctx, hipMalloc((void**)&c->d_all_hit[b], band_px * 4 * c->world));
             HIPCHK(ctx, hipMemset(c->d_band_hit[b], 0xff, band_px * 4));
@@ -152,16 +240,40 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = comm_reserve(c, cam->hsize, cam->vsize, want_hit);
     if (rc != RTX_OK) return rc;
-    const int b = (int)(c->seq & 1u);
-    if (c->used[b]) HIPCHK(ctx, hipStreamWaitEvent(st, c->ev_gather[b], 0));      // the set's previous gather has read it
+    const int b = (int)(c->seq % (unsigned)c->n_sets);
+    if (c->used[b] && (stats || ctx->opt.pipeline < 2)) HIPCHK(ctx, hipStreamWaitEvent(st, c->ev_gather[b], 0));   // the set's previous gather has read it
+    // asynchronous calls render on the set's own lane, behind whatever the caller's stream holds now; a call that wants
+    // its counts back is waited for anyway and stays on the caller's stream with the context's counters
+    hipStream_t rs = st;
+    rtx_ctx::Lane* lane = nullptr;
+    if (!stats && ctx->opt.pipeline >= 2) {
+        lane = &c->lane[b];
+        rs = lane->stream;
+        // behind whatever the caller's stream holds NOW — asked first, because an event recorded on an idle stream is not
+        // free: its marker lands on that stream's hardware queue, which may be the queue of the frame in flight, and the
+        // new frame would then wait for the old one to finish
+        if (hipStreamQuery(st) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(ctx, hipEventRecord(c->ev_call[b], st));
+            HIPCHK(ctx, hipStreamWaitEvent(rs, c->ev_call[b], 0));
+        }
+        if (c->used[b]) HIPCHK(ctx, hipStreamWaitEvent(rs, c->ev_gather[b], 0));
+        rc = rtx_check_sticky(ctx);
+        if (rc != RTX_OK) return rc;
+    }
+    auto render = [&](rtx_bands bands, void* d_rgb, void* d_hit, rtx_stats* out) {
+        return lane ? rtx_enqueue_render(ctx, scene, cam, max_depth, bands, flags | RTX_F_BANDS_COMPACT, d_rgb, d_hit, rs, lane,
+                                         c->d_counters[b], nullptr, nullptr, true)
+                    : rtx_render_device(ctx, scene, cam, max_depth, bands, flags | RTX_F_BANDS_COMPACT, d_rgb, d_hit, rs, out);
+    };
     if (c->loopback) {
         // every rank's share in turn, each where the all-gather would have put it
         const size_t band_px = (size_t)rows_padded(cam->vsize, c->world) * cam->hsize;
         rtx_stats sum{}, one{};
-        for (int r = 0; r < c->world; r++) {
-            rc = rtx_render_device(ctx, scene, cam, max_depth, rtx_bands{r, c->world}, flags | RTX_F_BANDS_COMPACT,
-                                   c->d_all[b] + (size_t)r * band_px * 3, want_hit ? c->d_all_hit[b] + (size_t)r * band_px : nullptr,
-                                   st, stats ? &one : nullptr);
+        const int n_shares = ctx->opt.debug == 3 ? 1 : c->world;    // (debug 3: rank 0's share only — tools/pipeline_probe.py)
+        for (int r = 0; r < n_shares; r++) {
+            rc = render(rtx_bands{r, c->world}, c->d_all[b] + (size_t)r * band_px * 3,
+                        want_hit ? c->d_all_hit[b] + (size_t)r * band_px : nullptr, stats ? &one : nullptr);
             if (rc != RTX_OK) return rc;
             if (stats) {
                 sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
@@ -172,10 +284,10 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
         }
         if (stats) *stats = sum;
     } else {
-        rc = rtx_render_device(ctx, scene, cam, max_depth, rtx_bands{c->rank, c->world}, flags | RTX_F_BANDS_COMPACT,
-                               c->d_band[b], want_hit ? c->d_band_hit[b] : nullptr, st, stats);
+        rc = render(rtx_bands{c->rank, c->world}, c->d_band[b], want_hit ? c->d_band_hit[b] : nullptr, stats);
         if (rc != RTX_OK) return rc;
     }
+    st = rs;
     HIPCHK(ctx, hipEventRecord(c->ev_render[b], st));
     c->cur = b; c->W = cam->hsize; c->H = cam->vsize; c->want_hit = want_hit;
     return RTX_OK;
@@ -297,10 +409,23 @@ void rtx_comm_destroy(rtx_comm* c) {
     (void)hipSetDevice(c->ctx->device);
     if (c->gstream) (void)hipStreamSynchronize(c->gstream);
     if (c->nccl && rccl()->so) (void)rccl()->CommDestroy(c->nccl);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < c->n_sets; b++) {
         for (void* p : {(void*)c->d_band[b], (void*)c->d_all[b], (void*)c->d_band_hit[b], (void*)c->d_all_hit[b]}) if (p) (void)hipFree(p);
         if (c->ev_render[b]) (void)hipEventDestroy(c->ev_render[b]);
         if (c->ev_gather[b]) (void)hipEventDestroy(c->ev_gather[b]);
+        if (c->ev_call[b]) (void)hipEventDestroy(c->ev_call[b]);
+        rtx_ctx::Lane& ln = c->lane[b];
+        if (ln.stream) {
+            (void)hipStreamSynchronize(ln.stream);
+            if (c->ctx->last_stream == ln.stream) c->ctx->last_stream = nullptr;
+            (void)hipStreamDestroy(ln.stream);
+        }
+        if (ln.side) (void)hipStreamDestroy(ln.side);
+        if (ln.ev_fork) (void)hipEventDestroy(ln.ev_fork);
+        if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
+        if (ln.d_lists) (void)hipFree(ln.d_lists);
+        if (ln.d_tile_counts) (void)hipFree(ln.d_tile_counts);
+        if (c->d_counters[b]) (void)hipFree(c->d_counters[b]);
     }
     if (c->gstream) (void)hipStreamDestroy(c->gstream);
     delete c;
@@ -308,6 +433,7 @@ void rtx_comm_destroy(rtx_comm* c) {
 
 int rtx_comm_rank(const rtx_comm* c) { return c ? c->rank : -1; }
 int rtx_comm_size(const rtx_comm* c) { return c ? c->world : 0; }
+int rtx_comm_concurrency(const rtx_comm* c) { return c ? c->n_concurrent : 0; }
 
 int rtx_render_gathered(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam, int max_depth, uint32_t flags,
                         void* d_frame, void* d_hit_frame, void* stream, rtx_stats* stats) {
@@ -324,7 +450,7 @@ int rtx_comm_wait(rtx_comm* c, void* stream) {
     rtx_ctx* ctx = c->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!stream) { HIPCHK(ctx, hipStreamSynchronize(c->gstream)); return rtx_ctx_poll(ctx, 0); }
-    const int last = (int)((c->seq + 1u) & 1u);                    // the set of the most recent frame
+    const int last = (int)((c->seq + (unsigned)c->n_sets - 1u) % (unsigned)c->n_sets);                    // the set of the most recent frame
     if (c->used[last]) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, c->ev_gather[last], 0));
     return RTX_OK;
 }

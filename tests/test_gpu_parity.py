@@ -581,6 +581,34 @@ def test_band_shares_of_2_3_8_ranks_assemble_to_the_full_frame_on_the_device(ctx
                         comm.close()
             finally:
                 sc.close()
+        # frames in flight: six frames of two cameras queued back to back without a wait in between (the communicator renders
+        # consecutive frames on alternating lanes, so they overlap on the GPU), each into a buffer of its own
+        pw, pc = rtx.load_yaml(parity.scene_text("S4", 333, 171))
+        sc = ctx.scene(pw)
+        try:
+            cam2 = rtx.load_yaml(parity.scene_text("S4", 200, 120))[1][0]
+            wants = [sc.render(pc[0], 5), sc.render(cam2, 5)]
+            for n_ranks, in_flight in ((3, 2), (2, 3), (1, 4), (2, 1)):
+                ctx.set_option("pipeline", in_flight)
+                comm = rtx.Comm.loopback(ctx, n_ranks)
+                try:
+                    assert 1 <= rtx.LIB.rtx_comm_concurrency(comm.h) <= in_flight + 1 or in_flight == 1
+                    frames = []
+                    for k in range(6):
+                        cam = (pc[0], cam2)[k & 1]
+                        f = hip.malloc(cam.vsize * cam.hsize * 3, 0x33); i = hip.malloc(cam.vsize * cam.hsize * 4, 0x44)
+                        bufs += [f, i]; frames.append((f, i, cam, wants[k & 1]))
+                        comm.render_gathered(sc, cam, f.value, i.value, 5)
+                    comm.wait()
+                    for f, i, cam, want in frames:
+                        assert np.array_equal(hip.to_host(f, cam.vsize * cam.hsize * 3, np.uint8).reshape(cam.vsize, cam.hsize, 3), want["rgb"]), (n_ranks, in_flight)
+                        assert np.array_equal(hip.to_host(i, cam.vsize * cam.hsize * 4, np.int32).reshape(cam.vsize, cam.hsize), want["hit"]), (n_ranks, in_flight)
+                finally:
+                    comm.close()
+                    ctx.set_option("pipeline", 2)
+            ctx.poll(wait=True)
+        finally:
+            sc.close()
     finally:
         for b in bufs:
             hip.lib.hipFree(b)
