@@ -144,7 +144,9 @@ void rtx_scene_destroy(rtx_scene*);
 /* Camera::render (camera.rs:39-54) + Canvas::to_image (canvas.rs:45-53): renders the selected
  * bands and copies RGB8 (and optional primary-hit ShapeIndex per pixel, -1 = miss) to host
  * buffers of hsize*vsize*3 bytes / hsize*vsize int32 (rows outside the bands are untouched;
- * with RTX_F_BANDS_COMPACT the buffers hold rtx_band_rows() rows).  hit may be NULL. */
+ * with RTX_F_BANDS_COMPACT the buffers hold rtx_band_rows() rows).  hit may be NULL.  A whole frame of many tiles
+ * is rendered in interleaved band sets whose copies to the host overlap the render of the next sets (same result;
+ * stats.kernel_ms then spans the first launch's start to the last launch's end; option "host_sets" / RTX_HOST_SETS). */
 int  rtx_render(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
                 uint32_t flags, uint8_t* rgb, int32_t* hit, rtx_stats* stats);
 

@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -503,6 +504,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.split_class = env_int("RTX_SPLIT_CLASS", 6);
     c->opt.debug = env_int("RTX_DEBUG", 0);
     c->opt.pipeline = env_int("RTX_PIPELINE", 2);
+    c->opt.host_sets = env_int("RTX_HOST_SETS", 0);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -576,6 +578,7 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "split_class") c->opt.split_class = value;
     else if (n == "debug") c->opt.debug = value;
     else if (n == "pipeline") c->opt.pipeline = value;
+    else if (n == "host_sets") c->opt.host_sets = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
 }
@@ -835,7 +838,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
             // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
             // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
-            const bool split = ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES;
+            const bool split = !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES);
             if (split && lane->side) {
                 rp.split_cap = n_tiles / 4 > 0 ? n_tiles / 4 : 1;
                 rp.split_min_class = ctx->opt.split_class;
@@ -866,6 +869,44 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     return RTX_OK;
 }
 
+// Streams, side streams, events and tile counts of lanes[0 .. n): everything a queued render on that lane needs.  The streams
+// of lanes 1.. are PICKED so that they really run beside the lanes before them (rtx_internal.h: hardware queues).
+int ensure_lanes(rtx_ctx* ctx, int n) {
+    if (n > rtx_ctx::kLanes) n = rtx_ctx::kLanes;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    bool need = false;
+    for (int l = 1; l < n; l++) need = need || !ctx->lanes[l].stream;
+    if (need) {
+        std::vector<hipStream_t> pool(2 * rtx_ctx::kLanes, nullptr), kept;
+        for (hipStream_t& p : pool) HIPCHK(ctx, hipStreamCreateWithFlags(&p, hipStreamNonBlocking));
+        for (int l = 0; l < n; l++) if (ctx->lanes[l].stream) kept.push_back(ctx->lanes[l].stream);
+        bool ok = true;
+        (void)rtx_spin_together({pool[0]}, &ok);                     // warm-up: code object load
+        for (int l = 1; l < n; l++) {
+            if (ctx->lanes[l].stream) continue;
+            size_t pick = pool.size();
+            for (size_t i = 0; i < pool.size() && pick == pool.size(); i++) {
+                if (!pool[i]) continue;
+                std::vector<hipStream_t> trial = kept; trial.push_back(pool[i]);
+                if (rtx_streams_overlap(trial)) pick = i;
+            }
+            for (size_t i = 0; i < pool.size() && pick == pool.size(); i++) if (pool[i]) pick = i;
+            ctx->lanes[l].stream = pool[pick]; kept.push_back(pool[pick]); pool[pick] = nullptr;
+        }
+        for (hipStream_t p : pool) if (p) (void)hipStreamDestroy(p);
+    }
+    for (int l = 0; l < n; l++) {
+        rtx_ctx::Lane& ln = ctx->lanes[l];
+        if (!ln.d_tile_counts) HIPCHK(ctx, hipMalloc((void**)&ln.d_tile_counts, 64 * sizeof(int32_t)));
+        if (!ln.side) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+        }
+    }
+    return RTX_OK;
+}
+
 // Sums the replicated counter block `rep` (already on the host) into *stats.
 int fill_stats(rtx_ctx* ctx, const rtx_camera* cam, rtx_bands bands, const unsigned long long* rep, float ms, rtx_stats* stats) {
     unsigned long long h[RTX_CNT_TOTAL] = {0};
@@ -893,7 +934,132 @@ int fill_stats(rtx_ctx* ctx, const rtx_camera* cam, rtx_bands bands, const unsig
     return RTX_OK;
 }
 
+// rtx_render of a large frame: the frame is cut into C interleaved band sets (set i = bands i, i + C, ...: every set is a
+// sample of the whole image, so the sets cost the same), rendered one after the other on two alternating lanes, each followed
+// on its lane by the copy of its compact buffer into pinned staging; the host moves a set's bands into the caller's
+// (pageable) image while the GPU renders the next sets.  One launch + one hipMemcpy left the GPU idle during the copy and the
+// copy engine idle during the render: S5 8K 20.7 -> see DESIGN.md 7.
+int render_chunked(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, uint32_t flags, int C,
+                   uint8_t* rgb, int32_t* hit, rtx_stats* stats) {
+    const size_t W = cam->hsize;
+    const int nb_total = (cam->vsize + RTX_TILE - 1) / RTX_TILE;
+    const size_t chunk_px = (size_t)((nb_total + C - 1) / C) * RTX_TILE * W;
+    int rc = rtx_check_sticky(ctx);
+    if (rc != RTX_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (C * chunk_px * 3 > ctx->rgb_cap) {
+        if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+        ctx->d_rgb = nullptr; ctx->rgb_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_rgb, C * chunk_px * 3));
+        ctx->rgb_cap = C * chunk_px * 3;
+    }
+    if (hit && C * chunk_px * 4 > ctx->hit_cap) {
+        if (ctx->d_hit) (void)hipFree(ctx->d_hit);
+        ctx->d_hit = nullptr; ctx->hit_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_hit, C * chunk_px * 4));
+        ctx->hit_cap = C * chunk_px * 4;
+    }
+    const size_t stage_bytes = C * chunk_px * (hit ? 7 : 3);
+    if (stage_bytes > ctx->stage_cap) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr; ctx->stage_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage, stage_bytes, hipHostMallocDefault));
+        ctx->stage_cap = stage_bytes;
+    }
+    if ((size_t)C > ctx->batch_cap) {
+        if (ctx->d_batch_counters) (void)hipFree(ctx->d_batch_counters);
+        ctx->d_batch_counters = nullptr; ctx->batch_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_batch_counters, (size_t)C * kCounterWords * sizeof(unsigned long long)));
+        ctx->batch_cap = C;
+    }
+    rc = ensure_lanes(ctx, 2);
+    if (rc != RTX_OK) return rc;
+    const size_t set_tiles = (size_t)((W + RTX_TILE - 1) / RTX_TILE) * ((nb_total + C - 1) / C);
+    for (int l = 0; l < 2; l++) {
+        rtx_ctx::Lane& ln = ctx->lanes[l];
+        if (scene->dev.has_branching && ln.tile_cap < set_tiles) {           // grow now: hipFree would stall the queue later
+            if (ln.d_lists) (void)hipFree(ln.d_lists);
+            ln.d_lists = nullptr; ln.tile_cap = 0;
+            HIPCHK(ctx, hipMalloc((void**)&ln.d_lists, (size_t)RTX_TILE_CLASSES * set_tiles * sizeof(int32_t)));
+            ln.tile_cap = set_tiles;
+        }
+    }
+    std::vector<hipEvent_t> ev((size_t)3 * C, nullptr);              // per set: begin, end (timed), landed in staging
+    auto drop_events = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (size_t i = 0; i < ev.size(); i++)
+        if ((i % 3 == 2 ? hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) : hipEventCreate(&ev[i])) != hipSuccess) {
+            drop_events(); return fail(ctx, RTX_E_DEVICE, "hipEventCreate failed");
+        }
+    uint8_t* const stage_hit = ctx->h_stage + C * chunk_px * 3;
+    for (int i = 0; i < C && rc == RTX_OK; i++) {
+        rtx_ctx::Lane& ln = ctx->lanes[i & 1];
+        rc = enqueue_render(ctx, scene, cam, max_depth, rtx_bands{i, C}, flags | RTX_F_BANDS_COMPACT | RTX_F_INTERNAL_NO_SPLIT,
+                            ctx->d_rgb + (size_t)i * chunk_px * 3, hit ? (void*)(ctx->d_hit + (size_t)i * chunk_px) : nullptr, ln.stream, &ln,
+                            ctx->d_batch_counters + (size_t)i * kCounterWords, ev[3 * i], ev[3 * i + 1]);
+        if (rc != RTX_OK) break;
+        if (hipMemcpyAsync(ctx->h_stage + (size_t)i * chunk_px * 3, ctx->d_rgb + (size_t)i * chunk_px * 3, chunk_px * 3, hipMemcpyDeviceToHost, ln.stream) != hipSuccess ||
+            (hit && hipMemcpyAsync(stage_hit + (size_t)i * chunk_px * 4, ctx->d_hit + (size_t)i * chunk_px, chunk_px * 4, hipMemcpyDeviceToHost, ln.stream) != hipSuccess) ||
+            hipEventRecord(ev[3 * i + 2], ln.stream) != hipSuccess)
+            rc = fail(ctx, RTX_E_DEVICE, "device to host copy failed");
+    }
+    // the host's share: a set's bands go to their rows as soon as the set has landed
+    for (int i = 0; i < C && rc == RTX_OK; i++) {
+        if (hipEventSynchronize(ev[3 * i + 2]) != hipSuccess) { rc = fail(ctx, RTX_E_DEVICE, "hipEventSynchronize failed"); break; }
+        for (int k = 0; i + k * C < nb_total; k++) {
+            const size_t y0 = (size_t)(i + k * C) * RTX_TILE;
+            size_t rows = cam->vsize - y0; if (rows > RTX_TILE) rows = RTX_TILE;
+            const size_t src_px = (size_t)i * chunk_px + (size_t)k * RTX_TILE * W;
+            std::memcpy(rgb + y0 * W * 3, ctx->h_stage + src_px * 3, rows * W * 3);
+            if (hit) std::memcpy(hit + y0 * W, stage_hit + src_px * 4, rows * W * 4);
+        }
+    }
+    // nothing of this call may still be running when it returns
+    for (int l = 0; l < 2; l++)
+        if (hipStreamSynchronize(ctx->lanes[l].stream) != hipSuccess && rc == RTX_OK) rc = fail(ctx, RTX_E_DEVICE, "hipStreamSynchronize failed");
+    if (rc == RTX_OK) {
+        std::vector<unsigned long long> rep((size_t)C * kCounterWords);
+        if (hipMemcpy(rep.data(), ctx->d_batch_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, RTX_E_DEVICE, "counter copy failed");
+        rtx_stats sum; std::memset(&sum, 0, sizeof sum);
+        for (int i = 0; i < C && rc == RTX_OK; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[0], ev[3 * i + 1]) != hipSuccess) { rc = fail(ctx, RTX_E_DEVICE, "hipEventElapsedTime failed"); break; }
+            rtx_stats one;
+            rc = fill_stats(ctx, cam, rtx_bands{i, C}, rep.data() + (size_t)i * kCounterWords, ms, &one);
+            sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
+            for (int k = 0; k < RTX_EV_COUNT; k++) sum.ev[k] += one.ev[k];
+            sum.overflow_pixels += one.overflow_pixels; sum.rays_shadow_skipped += one.rays_shadow_skipped;
+            if (one.kernel_ms > sum.kernel_ms) sum.kernel_ms = one.kernel_ms;      // first launch's begin to the last launch's end
+        }
+        if (stats) *stats = sum;
+    }
+    drop_events();
+    *ctx->h_sticky = 0;                               // this call reports its own overflow through the return code
+    return rc;
+}
+
 }  // namespace
+
+// ---- which streams really run side by side (rtx_internal.h)
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();                 // 100 MHz constant clock: the loop ends whatever happens
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+double rtx_spin_together(const std::vector<hipStream_t>& ss, bool* ok) {
+    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) *ok = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (hipStream_t s : ss) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, 10000ull);
+    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) *ok = false;
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+bool rtx_streams_overlap(const std::vector<hipStream_t>& ss) {
+    bool ok = true;
+    double best = 1e30;
+    for (int k = 0; k < 2; k++) { const double t = rtx_spin_together(ss, &ok); if (t < best) best = t; }
+    return ok && best < 160.0;
+}
 
 int rtx_check_sticky(rtx_ctx* ctx) {
     if (ctx->h_sticky && *ctx->h_sticky != 0)
@@ -952,6 +1118,23 @@ int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int 
     if (bands.first < 0 || bands.stride < 1) return fail(ctx, RTX_E_INVALID, "bad band selection");
     const bool compact = (flags & RTX_F_BANDS_COMPACT) != 0;
     const int nb = local_bands(cam->vsize, bands);
+    if (!compact && bands.first == 0 && bands.stride == 1) {
+        // whole frames of many tiles: render in interleaved band sets and copy each out while the next ones render
+        const long long n_tiles = (long long)((cam->hsize + RTX_TILE - 1) / RTX_TILE) * nb;
+        // how many sets: more sets hide more of the copy behind the render (what is left over is the last set's), but each set
+        // is a shorter dispatch with a tail and a probe of its own; scenes whose pixel costs span orders of magnitude
+        // (has_branching: the tail-bound ones) want few.  Measured with tools/host_latency.py
+        long long C = 1;
+        if (ctx->opt.host_sets > 0) C = ctx->opt.host_sets;
+        else if (n_tiles >= 8000) {
+            C = scene->dev.has_branching ? n_tiles / 32000 : n_tiles / 8000;
+            const long long hi = scene->dev.has_branching ? 4 : 8;
+            C = C < 2 ? 2 : (C > hi ? hi : C);
+        }
+        if (C > 8) C = 8;
+        if (C > nb) C = nb;
+        if (C >= 2) return render_chunked(ctx, scene, cam, max_depth, flags, (int)C, rgb, hit, stats);
+    }
     const size_t rows = compact ? (size_t)nb * RTX_TILE : (size_t)cam->vsize;
     const size_t npx = rows * cam->hsize;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1038,15 +1221,9 @@ int rtx_render_batch(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam
         const size_t t = (size_t)((cams[i].hsize + RTX_TILE - 1) / RTX_TILE) * ((cams[i].vsize + RTX_TILE - 1) / RTX_TILE);
         if (t > max_tiles) max_tiles = t;
     }
+    { const int lrc = ensure_lanes(ctx, n_lanes); if (lrc != RTX_OK) return lrc; }
     for (int l = 0; l < n_lanes; l++) {
         rtx_ctx::Lane& ln = ctx->lanes[l];
-        if (!ln.stream) HIPCHK(ctx, hipStreamCreate(&ln.stream));
-        if (!ln.d_tile_counts) HIPCHK(ctx, hipMalloc((void**)&ln.d_tile_counts, 64 * sizeof(int32_t)));
-        if (!ln.side) {
-            HIPCHK(ctx, hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
-        }
         if (scene->dev.has_branching && ln.tile_cap < max_tiles) {           // grow now: hipFree would stall the queue later
             if (ln.d_lists) (void)hipFree(ln.d_lists);
             ln.d_lists = nullptr; ln.tile_cap = 0;

@@ -18,6 +18,7 @@ struct rtx_opts {
     int split = -1;          // split tiles: -1 = default (short dispatches), 0 / 1 = forced
     int split_class = 6;     // tiles of this cost class and above are split
     int debug = 0;
+    int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
     int pipeline = 2;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
                              // 2..4; below 2 = every frame on the caller's stream)
 };
@@ -80,6 +81,13 @@ static inline int rtx_fail(rtx_ctx* c, int code, const std::string& msg) { if (c
 int rtx_enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,
                        uint32_t flags, void* d_rgb, void* d_hit, hipStream_t st, rtx_ctx::Lane* lane,
                        unsigned long long* d_counters, hipEvent_t ev_begin, hipEvent_t ev_end, bool may_allocate);
+// Which streams really run side by side: HIP maps streams onto a few hardware queues by a policy of its own, and launches on
+// streams that share a queue run one after the other.  rtx_spin_together: wall time (us) of one 100 us spin kernel on each of
+// the given (idle) streams, started together; rtx_streams_overlap: true if that is well under the serial time.
+double rtx_spin_together(const std::vector<hipStream_t>& streams, bool* ok);
+bool rtx_streams_overlap(const std::vector<hipStream_t>& streams);
+// internal flag bit of enqueue_render's `flags`: never use the SPLIT launch (the caller overlaps launches itself)
+constexpr uint32_t RTX_F_INTERNAL_NO_SPLIT = 1u << 16;
 // RTX_E_CAPACITY (and the message) if an earlier asynchronous render reported an overflow that nobody collected yet
 int rtx_check_sticky(rtx_ctx* ctx);
 

@@ -104,37 +104,15 @@ int nccl_fail(rtx_ctx* ctx, const char* what, ncclResult_t r) {
 }
 #define NCCLCHK(ctx, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return nccl_fail(ctx, #call, r_); } while (0)
 
-// ---- which streams really run side by side (see comm_finish_init)
-__global__ void spin_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();                 // 100 MHz constant clock: the loop ends whatever happens
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-// wall time of one 100 us spin on each of the given streams, started together; ~100 us if they overlap
-double spin_together(const std::vector<hipStream_t>& ss, bool* ok) {
-    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) *ok = false;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (hipStream_t s : ss) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, 10000ull);
-    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) *ok = false;
-    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-}
-
-bool overlap(rtx_ctx*, hipStream_t a, hipStream_t b) {
-    bool ok = true;
-    double best = 1e30;
-    for (int k = 0; k < 2; k++) { const double t = spin_together({a, b}, &ok); if (t < best) best = t; }
-    return ok && best < 160.0;
-}
-
 // greedy: keep a candidate if it overlaps with everything kept so far
 int pick_streams(rtx_ctx* ctx, const std::vector<hipStream_t>& pool, int want, std::vector<hipStream_t>* chosen) {
     bool ok = true;
-    (void)spin_together({pool[0]}, &ok);                            // warm-up: code object load
+    (void)rtx_spin_together({pool[0]}, &ok);                            // warm-up: code object load
     chosen->assign(1, pool[0]);
     for (size_t i = 1; i < pool.size() && (int)chosen->size() < want; i++) {
         std::vector<hipStream_t> trial = *chosen; trial.push_back(pool[i]);
         double best = 1e30;
-        for (int k = 0; k < 2; k++) { const double t = spin_together(trial, &ok); if (t < best) best = t; }
+        for (int k = 0; k < 2; k++) { const double t = rtx_spin_together(trial, &ok); if (t < best) best = t; }
         if (best < 160.0) chosen->push_back(pool[i]);
     }
     if (!ok) return rtx_fail(ctx, RTX_E_DEVICE, "stream calibration failed");
@@ -172,11 +150,11 @@ int comm_finish_init(rtx_comm* c) {
             for (size_t i = 0; i < rest.size() && best == rest.size(); i++) {
                 if (!rest[i]) continue;
                 std::vector<hipStream_t> trial = chosen; trial.push_back(rest[i]);
-                bool ok = true; double t = spin_together(trial, &ok); const double t2 = spin_together(trial, &ok); if (t2 < t) t = t2;
+                bool ok = true; double t = rtx_spin_together(trial, &ok); const double t2 = rtx_spin_together(trial, &ok); if (t2 < t) t = t2;
                 if (ok && t < 160.0) best = i;
             }
             for (size_t i = 0; i < rest.size() && best == rest.size(); i++)
-                if (rest[i] && overlap(ctx, c->lane[b].stream, rest[i])) best = i;
+                if (rest[i] && rtx_streams_overlap({c->lane[b].stream, rest[i]})) best = i;
             for (size_t i = 0; i < rest.size() && best == rest.size(); i++) if (rest[i]) best = i;
             c->lane[b].side = rest[best]; rest[best] = nullptr;
         }

@@ -549,6 +549,38 @@ def test_render_device_writes_device_buffers_on_the_callers_stream(ctx):
         hip.lib.hipStreamDestroy(st)
 
 
+def test_host_render_in_band_sets_equals_one_launch(ctx):
+    """rtx_render of a whole frame into host buffers renders large frames as 2..8 interleaved band sets on two lanes and copies
+    each set out while the next ones render (option host_sets; 0 = by frame size).  Forced here on small ragged frames:
+    image, hit ids, ray counts and event counts must equal the one-launch path's."""
+    import rtx
+    try:
+        for name, w, h in (("S4", 333, 171), ("S5", 200, 97), ("S1", 64, 9), ("S3", 160, 120)):
+            pw, pc = rtx.load_yaml(parity.scene_text(name, w, h))
+            sc = ctx.scene(pw)
+            try:
+                ctx.set_option("host_sets", 1)
+                want = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
+                for sets in (2, 3, 8):
+                    ctx.set_option("host_sets", sets)
+                    for want_hit in (True, False):
+                        got = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS, want_hit=want_hit)
+                        assert np.array_equal(got["rgb"], want["rgb"]), (name, sets)
+                        if want_hit:
+                            assert np.array_equal(got["hit"], want["hit"]), (name, sets)
+                        a, b = got["stats"], want["stats"]
+                        assert (a.rays_primary, a.rays_shadow, a.rays_secondary, a.rays_shadow_skipped) == \
+                               (b.rays_primary, b.rays_shadow, b.rays_secondary, b.rays_shadow_skipped), (name, sets)
+                        ea, eb = a.events(), b.events()
+                        for k in eb:
+                            if k not in ("lane_slots", "op_slots"):
+                                assert ea[k] == eb[k], (name, sets, k)
+            finally:
+                sc.close()
+    finally:
+        ctx.set_option("host_sets", 0)
+
+
 def test_band_shares_of_2_3_8_ranks_assemble_to_the_full_frame_on_the_device(ctx):
     """The N > 1 data path without RCCL: a loopback communicator (rtx_comm_init_loopback) renders the compact band sets of
     all N ranks on this one GPU, each where the all-gather would have delivered it, and the product's de-interleave kernel
