@@ -501,7 +501,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.tile_mul = env_int("RTX_TILE_MUL", 7919);
     c->opt.probe_depth = env_int("RTX_PROBE_DEPTH", 2);
     c->opt.split = env_int("RTX_SPLIT", -1);
-    c->opt.split_class = env_int("RTX_SPLIT_CLASS", 6);
+    c->opt.split_class = env_int("RTX_SPLIT_CLASS", 7);
     c->opt.debug = env_int("RTX_DEBUG", 0);
     c->opt.pipeline = env_int("RTX_PIPELINE", 2);
     c->opt.host_sets = env_int("RTX_HOST_SETS", 0);

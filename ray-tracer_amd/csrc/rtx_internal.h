@@ -16,7 +16,7 @@ struct rtx_opts {
     int tile_mul = 7919;     // multiplier of the tile permutation
     int probe_depth = 2;     // depth budget of the tile-cost probe launch
     int split = -1;          // split tiles: -1 = default (short dispatches), 0 / 1 = forced
-    int split_class = 6;     // tiles of this cost class and above are split
+    int split_class = 7;     // tiles of this cost class and above are split
     int debug = 0;
     int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
     int pipeline = 2;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;

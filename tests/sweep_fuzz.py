@@ -32,7 +32,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
             ok = ok and all(ge[k] == ce[k] for k in rtapi.REF_EVENTS if k != "pow")
         ctx.options(lpt=1, split=1, split_class=2)
         fast = ctx.render(pw, pcs[0], depth)
-        ctx.options(lpt=-1, split=-1, split_class=6)
+        ctx.options(lpt=-1, split=-1, split_class=7)
         ok = ok and np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]) and fast["stats"].rays == gs.rays
         ties += r["tie_pixels"]; tie_scenes = globals().get("tie_scenes", 0) + (1 if r["tie_pixels"] else 0); tie_mis = globals().get("tie_mis", 0) + r["id_mismatch_incl_ties"]
         if not ok:

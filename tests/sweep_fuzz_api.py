@@ -33,7 +33,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
             ok = ok and all(ge[k] == ce[k] for k in rtapi.REF_EVENTS if k != "pow")
         ctx.options(lpt=1, split=1, split_class=2)
         fast = ctx.render(pw, pc, depth)
-        ctx.options(lpt=-1, split=-1, split_class=6)
+        ctx.options(lpt=-1, split=-1, split_class=7)
         ok = ok and np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]) and fast["stats"].rays == gs.rays
         if i % 5 == 0:
             # band subsets (row-interleaved, plain and compact) and a batch of two cameras against single renders

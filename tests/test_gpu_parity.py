@@ -308,7 +308,7 @@ def test_split_tiles_do_not_change_the_image(ctx, monkeypatch, name, w, h):
             sc.render(pc[0], 5, bands=(g, 3), out=(rgb, hit))
         assert np.array_equal(rgb, a["rgb"]) and np.array_equal(hit, a["hit"])
     finally:
-        ctx.options(lpt=-1, split=-1, split_class=6)
+        ctx.options(lpt=-1, split=-1, split_class=7)
         sc.close()
 
 
@@ -331,7 +331,7 @@ def test_split_tiles_on_the_torture_scene(ctx, monkeypatch):
             ea, eb = a["stats"].events(), b["stats"].events()
             assert {k: ea[k] for k in rtapi.REF_EVENTS} == {k: eb[k] for k in rtapi.REF_EVENTS}, cls
     finally:
-        ctx.options(lpt=-1, split=-1, split_class=6)
+        ctx.options(lpt=-1, split=-1, split_class=7)
 
 
 def test_randomized_scene_files_parity(ctx):
@@ -741,10 +741,10 @@ def test_async_overflow_is_sticky_not_silent(ctx):
         assert e.value.code == rtx.E_CAPACITY and "guard" in str(e.value)
         ctx.options(debug=0)
         ok = sc.render(pc[0], 5)                                    # with the real guard the same frame renders
-        ctx.options(lpt=-1, split=-1, split_class=6)
+        ctx.options(lpt=-1, split=-1, split_class=7)
         assert np.array_equal(ok["rgb"], sc.render(pc[0], 5)["rgb"])
     finally:
-        ctx.options(lpt=-1, split=-1, split_class=6, debug=0)
+        ctx.options(lpt=-1, split=-1, split_class=7, debug=0)
         rtx.LIB.rtx_ctx_poll(ctx.h, 1)
         sc.close()
         hip.lib.hipFree(buf)

@@ -49,7 +49,7 @@ def test_noalloc_entry_point_matches_render_device():
         # second call: a smaller, ragged frame of another scene (CSG kernel), bands 1 of 3, compact
         cases = [("S4", 640, 360, (0, 1), 0, dict(lpt=1, split=1, split_class=4)),
                  ("S5", 333, 171, (1, 3), rtx.F_BANDS_COMPACT, dict(lpt=1, split=1, split_class=2)),
-                 ("S1", 101, 53, (0, 1), 0, dict(lpt=-1, split=-1, split_class=6))]
+                 ("S1", 101, 53, (0, 1), 0, dict(lpt=-1, split=-1, split_class=7))]
         for name, w, h, bands, flags, opts in cases:
             pw, pc = rtx.load_yaml(parity.scene_text(name, w, h))
             sc = ctx.scene(pw)
@@ -80,7 +80,7 @@ def test_noalloc_entry_point_matches_render_device():
         finally:
             sc.close()
     finally:
-        ctx.options(lpt=-1, split=-1, split_class=6)
+        ctx.options(lpt=-1, split=-1, split_class=7)
         for b in bufs:
             hip.lib.hipFree(b)
         hip.lib.hipStreamDestroy(st)

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ray-tracer_amd", "python"), os.path.join(ROOT, "tools")]
 import rtx, scenes
 ctx = rtx.Context(0)
+ctx.set_option("host_sets", 1)          # one launch per render: this probe is about the launch itself
 CLS = os.environ.get("PROBE_CLASSES", "7,6,5,4").split(",")     # split classes >= c
 
 
