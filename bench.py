@@ -282,7 +282,7 @@ def main():
     out = None
     if rank == 0:
         gather = ("row-interleaved 8-row bands x%d + one ncclAllGather per frame inside the product (rtx_render_gathered), "
-                  "two frames in flight on alternating render lanes" % N) if comm is not None else \
+                  "up to three frames in flight on alternating render lanes" % N) if comm is not None else \
                  ("row-interleaved 8-row bands x%d, gloo REHEARSAL gather through host memory" % N if N > 1 else "1 GPU")
         m["roofline"]["note"] = ("achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events (counted by a "
                                  "pass in the reference-faithful mode: is_shadowed visits everything, as world.rs:196-206 does) x the survey's "

@@ -219,7 +219,7 @@ int  rtx_comm_size(const rtx_comm*);
 int  rtx_comm_concurrency(const rtx_comm*);
 
 /* Camera::render (camera.rs:39-54) on all ranks of `comm`: queues this rank's bands, then the all-gather and the
- * de-interleave on the communicator's own stream.  Consecutive calls render on alternating internal render lanes (two
+ * de-interleave on the communicator's own stream.  Consecutive calls render on alternating internal render lanes (three
  * frames in flight by default; option "pipeline" / RTX_PIPELINE = 1..4, read when the communicator is created), each
  * behind the work `stream` (NULL = the context's) holds at the time of the call: the start of frame k+1 fills the wave
  * slots the tail of frame k leaves idle, and its render overlaps frame k's gather.  Later work on `stream` does NOT wait

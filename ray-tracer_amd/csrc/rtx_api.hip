@@ -503,8 +503,9 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.split = env_int("RTX_SPLIT", -1);
     c->opt.split_class = env_int("RTX_SPLIT_CLASS", 7);
     c->opt.debug = env_int("RTX_DEBUG", 0);
-    c->opt.pipeline = env_int("RTX_PIPELINE", 2);
+    c->opt.pipeline = env_int("RTX_PIPELINE", 3);
     c->opt.host_sets = env_int("RTX_HOST_SETS", 0);
+    c->opt.stream_lpt = env_int("RTX_STREAM_LPT", -1);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -579,6 +580,7 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "debug") c->opt.debug = value;
     else if (n == "pipeline") c->opt.pipeline = value;
     else if (n == "host_sets") c->opt.host_sets = value;
+    else if (n == "stream_lpt") c->opt.stream_lpt = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
 }
@@ -811,7 +813,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     // then varies by two orders of magnitude) and the dispatch is long; RTX_LPT=0/1 overrides.
     {
         const int n_tiles = rp.tiles_x * rp.n_bands_local;
-        const bool want = ctx->opt.lpt >= 0 ? ctx->opt.lpt != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching);
+        const bool want = !(flags & RTX_F_INTERNAL_NO_LPT) && (ctx->opt.lpt >= 0 ? ctx->opt.lpt != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching));
         if (want && n_tiles > 0) {
             if (lane->tile_cap < (size_t)n_tiles) {
                 if (!may_allocate) return fail(ctx, RTX_E_CAPACITY, "frame has more tiles than the no-alloc scratch holds");

@@ -18,8 +18,9 @@ struct rtx_opts {
     int split = -1;          // split tiles: -1 = default (short dispatches), 0 / 1 = forced
     int split_class = 7;     // tiles of this cost class and above are split
     int debug = 0;
+    int stream_lpt = -1;     // streaming callers of rtx_render_gathered keep the tile-order probe: -1 = by dispatch length, 0 / 1 = forced
     int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
-    int pipeline = 2;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
+    int pipeline = 3;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
                              // 2..4; below 2 = every frame on the caller's stream)
 };
 
@@ -88,6 +89,8 @@ double rtx_spin_together(const std::vector<hipStream_t>& streams, bool* ok);
 bool rtx_streams_overlap(const std::vector<hipStream_t>& streams);
 // internal flag bit of enqueue_render's `flags`: never use the SPLIT launch (the caller overlaps launches itself)
 constexpr uint32_t RTX_F_INTERNAL_NO_SPLIT = 1u << 16;
+// ... and: no tile-order probe either (plain permuted order)
+constexpr uint32_t RTX_F_INTERNAL_NO_LPT = 1u << 17;
 // RTX_E_CAPACITY (and the message) if an earlier asynchronous render reported an overflow that nobody collected yet
 int rtx_check_sticky(rtx_ctx* ctx);
 

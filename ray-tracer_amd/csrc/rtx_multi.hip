@@ -239,8 +239,24 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
         rc = rtx_check_sticky(ctx);
         if (rc != RTX_OK) return rc;
     }
+    // a caller that streams frames (the previous frame is still rendering when this one is queued) is after throughput: the
+    // tail of a frame is filled by the start of the next, so the measures that shorten ONE frame's critical path at the
+    // price of extra work (the 4-way SPLIT launch; for short dispatches also the tile-order probe) are left out.  A caller
+    // that waits for every frame gets them as before.
+    uint32_t sched = 0;
+    if (lane && c->seq > 0) {
+        const int prev = (int)((c->seq - 1u) % (unsigned)c->n_sets);
+        if (hipEventQuery(c->ev_render[prev]) == hipErrorNotReady) {
+            // (the probe still pays for long dispatches: measured on S4 with three frames in flight, tools/pipeline_probe.py,
+            // with / without it: 4.14 / 4.36 ms at N = 1, 2.14 / 2.18 at N = 2, 1.17 / 1.15 at N = 4, 0.67 / 0.63 at N = 8)
+            const long long share_tiles = (long long)((cam->hsize + RTX_TILE - 1) / RTX_TILE) * (rows_padded(cam->vsize, c->world) / RTX_TILE);
+            const bool keep_probe = ctx->opt.stream_lpt >= 0 ? ctx->opt.stream_lpt != 0 : share_tiles >= 40000;
+            sched = RTX_F_INTERNAL_NO_SPLIT | (keep_probe ? 0u : RTX_F_INTERNAL_NO_LPT);
+        }
+        (void)hipGetLastError();
+    }
     auto render = [&](rtx_bands bands, void* d_rgb, void* d_hit, rtx_stats* out) {
-        return lane ? rtx_enqueue_render(ctx, scene, cam, max_depth, bands, flags | RTX_F_BANDS_COMPACT, d_rgb, d_hit, rs, lane,
+        return lane ? rtx_enqueue_render(ctx, scene, cam, max_depth, bands, flags | RTX_F_BANDS_COMPACT | sched, d_rgb, d_hit, rs, lane,
                                          c->d_counters[b], nullptr, nullptr, true)
                     : rtx_render_device(ctx, scene, cam, max_depth, bands, flags | RTX_F_BANDS_COMPACT, d_rgb, d_hit, rs, out);
     };

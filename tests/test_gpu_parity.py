@@ -637,7 +637,7 @@ def test_band_shares_of_2_3_8_ranks_assemble_to_the_full_frame_on_the_device(ctx
                         assert np.array_equal(hip.to_host(i, cam.vsize * cam.hsize * 4, np.int32).reshape(cam.vsize, cam.hsize), want["hit"]), (n_ranks, in_flight)
                 finally:
                     comm.close()
-                    ctx.set_option("pipeline", 2)
+                    ctx.set_option("pipeline", 3)
             ctx.poll(wait=True)
         finally:
             sc.close()
