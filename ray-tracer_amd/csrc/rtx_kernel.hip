@@ -363,7 +363,11 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 #pragma unroll
         for (int i = 0; i < RTX_EV_USED; i++) ev[i] = 0;
     }
+#ifdef RTX_DIAG_PHASE
+#define EV(e, n) do { if (COUNT && (e) != RTX_EV_POW && (e) != RTX_EV_SCHLICK && (e) != RTX_EV_REFR && (e) != RTX_EV_BACKFACE) ev[e] += (n); } while (0)
+#else
 #define EV(e, n) do { if (COUNT) ev[e] += (n); } while (0)
+#endif
 #ifdef RTX_TIMING
     unsigned long long tm_ffwd = 0, tm_body = 0, tm_shade = 0, tm_other = 0, tm_prep = 0, tm_light = 0, tm_mark = __builtin_amdgcn_s_memtime();
 #define TM(acc) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_mark; tm_mark = now_; } while (0)
@@ -466,11 +470,29 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
 
+    bool phaseR = false;                  // the kind of ray the last iteration traced (see the top of the loop)
     bool guard_hit = false;
     int guard = 0;                        // SPLIT: a wave whose lanes wait for each other must still end (it cannot happen by
                                           // construction — helpers never wait for their owners — but a hung wave hangs the GPU)
     while (__any(mode != MODE_DONE || (SPLIT && waiting))) {
         if (SPLIT && ++guard > rp.split_guard) { guard_hit = true; break; }
+        // ---- one KIND of ray per iteration.  A lane alternates radiance and shadow traces, and the two kinds end in different
+        // shading blocks (PreparedComputations / lighting + children), ~450 vector instructions each.  Lanes fall out of step
+        // whenever a radiance ray misses or a shadow ray is skipped, and a wave whose lanes are at both kinds runs BOTH blocks
+        // in one iteration (27 % of S4's iterations did).  So when both kinds wait, only one of them is traced — the kinds take
+        // turns — and the lanes of the other sit this iteration out (as MODE_DONE: they keep their state and their ray in
+        // slot 0), which puts them back in step with the rest: S4 4.80 -> 4.55 ms.  (Letting the larger group go first was
+        // measured too: no gain — the lanes that sit out repeatedly become the tail.)  Not in SPLIT waves: their idle lanes
+        // are the helpers.
+        const int saved_mode = mode;
+        bool hold = false;
+        if (!SPLIT && !PROBE) {
+            const bool wantR = mode == MODE_RADIANCE, wantS = mode == MODE_SHADOW;
+            const unsigned long long mR = __ballot(wantR), mS = __ballot(wantS);
+            phaseR = (mR != 0 && mS != 0) ? !phaseR : mR != 0;
+            hold = (wantR && !phaseR) || (wantS && phaseR);
+            if (hold) mode = MODE_DONE;
+        }
         TML(tm_shade);
         // ================================================================= TRACE
         // World::intersect (world.rs:111-118) for every lane's current ray.
@@ -490,7 +512,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         bool decided = false;             // shadow ray already answered (world.rs:203-206)
         int cnt = 0;                      // CSG list length
         uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
-        const bool is_shadow = mode == MODE_SHADOW;
+        // (wave-uniform where the kinds take turns: the early-out tests and the container bookkeeping below become scalar branches)
+        const bool is_shadow = (!SPLIT && !PROBE) ? !phaseR : mode == MODE_SHADOW;
 
         // The running state is ORDER-INDEPENDENT: ties in t resolve by op index (= the reference's visiting
         // order, which its stable sorts preserve), so shapes of one run may be fed in any order.
@@ -515,8 +538,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 if (k == 2 && t1 >= 0.0) {
                     if (closer(t1, shape)) { best_t = t1; best_op = shape; best_inside = true; }
                 }
-                // exactly one negative entry -> the shape is an open container behind the origin
-                if (k == 1 || t1 >= 0.0) enter(t0, shape);
+                // exactly one negative entry -> the shape is an open container behind the origin (only a radiance ray's
+                // hit asks for its containers: world.rs:258-296 runs inside PreparedComputations)
+                if (!is_shadow && (k == 1 || t1 >= 0.0)) enter(t0, shape);
             }
         };
 
@@ -1117,6 +1141,14 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         }
 
         TM(tm_other);
+#ifdef RTX_DIAG_PHASE
+        // diagnostic: how often a wave's lanes are at BOTH kinds of shading in one iteration (ev pow = iterations with a
+        // radiance lane, ev schlick = with a shadow lane, ev refr = with both, ev backface = all iterations)
+        if (COUNT) {
+            const bool anyR = __any(mode == MODE_RADIANCE), anyS = __any(mode == MODE_SHADOW);
+            if (lane == 0) { ev[RTX_EV_POW] += anyR; ev[RTX_EV_SCHLICK] += anyS; ev[RTX_EV_REFR] += anyR && anyS; ev[RTX_EV_BACKFACE] += 1; }
+        }
+#endif
         // ================================================================= SHADE
         bool returning = false;                 // lane has a finished colour to hand to its parent frame
         double rr = 0.0, rg = 0.0, rb = 0.0;
@@ -1478,6 +1510,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             org_base[0] = nro.x; org_base[64] = nro.y; org_base[128] = nro.z;
             dir_base[0] = nrd.x; dir_base[64] = nrd.y; dir_base[128] = nrd.z;
         }
+        if (hold) mode = saved_mode;
     }
 
 #ifdef RTX_TIMING

@@ -4,6 +4,7 @@ computes (the all-gather is not included).  usage: band_probe.py [S3 S4 S5 ...];
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ray-tracer_amd", "python"), os.path.join(ROOT, "tools")]
+os.environ.setdefault("RTX_HOST_SETS", "1")     # one launch per render: these tools time the launch itself
 import rtx, scenes
 from bench import WORKLOADS
 ctx = rtx.Context(0)

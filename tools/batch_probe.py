@@ -8,6 +8,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [HERE, os.path.join(HERE, "..", "ray-tracer_amd", "python")]
+os.environ.setdefault("RTX_HOST_SETS", "1")     # one launch per render: these tools time the launch itself
 import rtx      # noqa: E402
 import scenes   # noqa: E402
 

@@ -3,6 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ray-tracer_amd", "python"), os.path.join(ROOT, "tools")]
+os.environ.setdefault("RTX_HOST_SETS", "1")     # one launch per render: these tools time the launch itself
 import rtx, scenes
 from bench import WORKLOADS
 name = sys.argv[1] if len(sys.argv) > 1 else "S4"

@@ -6,6 +6,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ray-tracer_amd", "python"), os.path.join(ROOT, "tools")]
 import numpy as np
+os.environ.setdefault("RTX_HOST_SETS", "1")     # one launch per render: these tools time the launch itself
 import rtx, scenes
 name, w, h, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 os.environ["RTX_SPLIT"] = sys.argv[5] if len(sys.argv) > 5 else "0"
