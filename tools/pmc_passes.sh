@@ -9,8 +9,9 @@ run() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_${tag}_${name} -o $wl -- python3 bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 1 --workload $wl > gpurun_out/pmc_${tag}_${name}.log 2>&1
 }
-run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
-run sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
+# (GRBM_GUI_ACTIVE rides in the SAME pass as the counters it is divided into: kernel times differ by 10 % from pass to pass)
+run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
+run sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetchsz FETCH_SIZE
 run write WRITE_SIZE
