@@ -484,13 +484,13 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // slot 0), which puts them back in step with the rest: S4 4.80 -> 4.55 ms.  (Letting the larger group go first was
         // measured too: no gain — the lanes that sit out repeatedly become the tail.)  Not in SPLIT waves: their idle lanes
         // are the helpers.
-        const int saved_mode = mode;
-        bool hold = false;
+        unsigned long long hold_mask = 0;     // (a wave mask in scalar registers, not a per-lane flag: nothing more to keep live per lane)
         if (!SPLIT && !PROBE) {
             const bool wantR = mode == MODE_RADIANCE, wantS = mode == MODE_SHADOW;
             const unsigned long long mR = __ballot(wantR), mS = __ballot(wantS);
             phaseR = (mR != 0 && mS != 0) ? !phaseR : mR != 0;
-            hold = (wantR && !phaseR) || (wantS && phaseR);
+            const bool hold = (wantR && !phaseR) || (wantS && phaseR);
+            hold_mask = __ballot(hold);
             if (hold) mode = MODE_DONE;
         }
         TML(tm_shade);
@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             org_base[0] = nro.x; org_base[64] = nro.y; org_base[128] = nro.z;
             dir_base[0] = nrd.x; dir_base[64] = nrd.y; dir_base[128] = nrd.z;
         }
-        if (hold) mode = saved_mode;
+        if ((hold_mask >> lane) & 1ull) mode = phaseR ? MODE_SHADOW : MODE_RADIANCE;     // the kind that sat out
     }
 
 #ifdef RTX_TIMING
