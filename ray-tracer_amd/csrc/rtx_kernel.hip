@@ -1295,6 +1295,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     light_k++;
                 }
             }
+            if (PROBE && light_k < n_lights) {
+                // the probe only estimates how many rays a tile's pixels need: a shadow ray spawns nothing, so it is counted
+                // and not traced (the probe is bound by the length of its longest chain of rays, which this halves)
+                n_shadow += (unsigned)(n_lights - light_k);
+                light_k = n_lights;
+            }
             if (light_k >= n_lights) lights_done = true;
         }
         if (shading && !lights_done) {
