@@ -121,7 +121,8 @@ void cull_sphere(const double* inverse16, const double* lc, double lr, float* ou
 struct OpRec {
     int32_t kind, level, skip, flags, shape, clevel, xf;
     float cull[4];       // bounding sphere from the node's own extent / its local bounds (what the reference's bounds test implies)
-    float cull_t[4];     // CSG: the tighter sphere of where SURVIVING hits can lie (extent_sphere below); else = cull
+    float cull_t[4];     // the product's sphere: shapes = cull; containers: around the children themselves (geom_sphere), CSG: around
+                         // where SURVIVING hits can lie (extent_sphere) when that is tighter
     double inv[12], w33, bounds[6];
 };
 
@@ -176,6 +177,41 @@ struct Compiler {
         return o;
     }
 
+    // The product's pre-test sphere of a container (OpRec::cull_t) must bound its GEOMETRY, not the reference's bounds: the
+    // kernel tests it against the HALF-line t >= 0 too (children wholly behind the ray origin), and the reference's group
+    // bounds need not contain the children — Bounds::from_points (bounds.rs:29-40) seeds `max` with the second corner and
+    // never looks at the first, and a plane's infinite box turns into NaN / garbage under a rotation — while its bounds test
+    // (bounds.rs:42-54) is one against the whole line.  A ray that misses the sphere around the bounds gets an empty list
+    // from the reference at any t (that sphere, OpRec::cull, serves the whole-line test of the counting mode); a HALF-line
+    // that misses a sphere around the children themselves cannot hit a child at t >= 0, whatever the bounds say.  Found by
+    // the randomized sweep (tests/sweep_fuzz.py): 24 of 1 500 scenes, all with rotated groups, differed in a few pixels.
+    // Children = the ops between b + 1 and the end of `ops`, hopping over nested containers (whose spheres are final).
+    void geom_sphere(int node, int b) {
+        float* out = ops[b].cull_t;
+        out[0] = out[1] = out[2] = 0.f; out[3] = INFINITY;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        std::vector<const float*> ch;
+        for (size_t j = (size_t)b + 1; j < ops.size();) {
+            const OpRec& o = ops[j];
+            const bool cont = o.kind == OPK_GROUP_BEGIN || o.kind == OPK_CSG_BEGIN;
+            if (o.kind <= OPK_CUBE || cont) {
+                if (!std::isfinite(o.cull_t[3])) return;                 // a plane (or a container with one) below: unbounded
+                ch.push_back(o.cull_t);
+                const double r = std::sqrt((double)o.cull_t[3]);
+                for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], o.cull_t[k] - r); hi[k] = std::fmax(hi[k], o.cull_t[k] + r); }
+            }
+            j = cont ? (size_t)o.skip : j + 1;
+        }
+        if (ch.empty()) return;                                          // (an empty group has no hits; it is never visited for long)
+        const double c[3] = {(lo[0] + hi[0]) * 0.5, (lo[1] + hi[1]) * 0.5, (lo[2] + hi[2]) * 0.5};
+        double R = 0.0;
+        for (const float* s4 : ch) {
+            const double dx = s4[0] - c[0], dy = s4[1] - c[1], dz = s4[2] - c[2];
+            R = std::fmax(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s4[3]));
+        }
+        cull_sphere(d->node_inverse + (size_t)node * 16, c, R * 1.0001, out);
+    }
+
     // Where can hits that SURVIVE a CSG's filter (csg.rs:94-136) lie?  Union: on either child; intersection: left hits inside
     // the right child and right hits inside the left one, i.e. inside BOTH; difference: left hits outside the right child and
     // right hits inside the left one, i.e. inside the LEFT child.  A ray that misses a bounding sphere of that region gets an
@@ -205,7 +241,7 @@ struct Compiler {
         }
         float t4[4];
         cull_sphere(d->node_inverse + (size_t)node * 16, c, r * 1.0001, t4);
-        if (std::isfinite(t4[3]) && (!std::isfinite(ops[begin].cull[3]) || t4[3] < ops[begin].cull[3])) std::memcpy(ops[begin].cull_t, t4, sizeof t4);
+        if (std::isfinite(t4[3]) && (!std::isfinite(ops[begin].cull_t[3]) || t4[3] < ops[begin].cull_t[3])) std::memcpy(ops[begin].cull_t, t4, sizeof t4);
     }
 
     // returns the number of list entries the subtree can produce (for the CSG capacity check)
@@ -249,6 +285,7 @@ struct Compiler {
             org_depth += xf != XF_IDENTITY; dir_depth += xf == XF_GENERAL;
             max_org = std::max(max_org, org_depth); max_dir = std::max(max_dir, dir_depth);
             for (int i = 0; i < nc; i++) entries += emit(d->children[fc + i], level + 1, list, clevel + 1);
+            if (err == RTX_OK) geom_sphere(node, b);
             org_depth -= xf != XF_IDENTITY; dir_depth -= xf == XF_GENERAL;
             stack.pop_back();
             if (list) ops.push_back(make(-1, OPK_GROUP_END, level, lf, clevel));   // outside CSG an END has nothing to do
@@ -274,7 +311,7 @@ struct Compiler {
             OpRec om = make(-1, OPK_CSG_MID, level, f, cl); om.shape = cop; ops.push_back(om);
             const int right_op = (int)ops.size();
             entries += emit(d->children[fc + 1], level + 1, true, cl + 1);
-            if (err == RTX_OK) extent_sphere(node, b, left_op, right_op, cop);
+            if (err == RTX_OK) { geom_sphere(node, b); extent_sphere(node, b, left_op, right_op, cop); }
             org_depth -= xf != XF_IDENTITY; dir_depth -= xf == XF_GENERAL;
             stack.pop_back();
             OpRec oe = make(-1, OPK_CSG_END, level, f, cl); oe.shape = cop; ops.push_back(oe);

@@ -41,7 +41,12 @@ def assert_parity(gpu, cpu, label="", max_tie_frac=0.005):
     r = compare(gpu, cpu)
     assert r["id_mismatch"] == 0, (label, r)
     assert r["within1"] >= 0.999, (label, r)
-    assert r["tie_pixels"] <= (max(8, int(max_tie_frac * r["n"])) if max_tie_frac > 0 else 0), (label, "too many tie pixels", r)
+    limit = max(8, int(max_tie_frac * r["n"])) if max_tie_frac > 0 else 0
+    if max_tie_frac > 0 and r["tie_pixels"] > limit:
+        # a scene full of coincident surfaces (generated scenes do that: a plane through a CSG face): no exemption at all then
+        assert r["id_mismatch_incl_ties"] == 0, (label, "too many tie pixels for the exemption, and ids differ inside them", r)
+    else:
+        assert r["tie_pixels"] <= limit, (label, "too many tie pixels", r)
     return r
 
 

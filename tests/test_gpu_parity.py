@@ -2,6 +2,8 @@
 oracle on the same seeded scenes, at sizes the oracle finishes in seconds.  Bars: hit ids
 bit-exact away from EPSILON-tie pixels, RGB8 within +-1 LSB on >= 99.9 % of pixels
 (BASELINE.json north_star), ray counts and event counts exactly equal."""
+import os
+
 import numpy as np
 import pytest
 
@@ -348,7 +350,7 @@ def test_randomized_scene_files_parity(ctx):
     import yaml_scene
     rng = np.random.default_rng(20261111)
     done = skipped = ties = px = tie_mis = 0
-    for i in range(40):
+    for i in range(120):
         text = fuzz_scenes.make(rng)
         depth = (5, 0, 1, 3, 8)[i % 5]
         pw, pcs = rtx.load_yaml(text)
@@ -372,10 +374,38 @@ def test_randomized_scene_files_parity(ctx):
             assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}, i
         fast = ctx.render(pw, pcs[0], depth)
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
-        ties += r["tie_pixels"]; done += 1
-    assert done >= 30, (done, skipped)
+        # (a scene over the per-scene bound had to match without any exemption: its flags do not count as exempted pixels)
+        ties += r["tie_pixels"] if r["tie_pixels"] <= 0.25 * r["n"] else 0; done += 1
+    assert done >= 90, (done, skipped)
     print("randomized scene files: %d scenes, %d pixels, %d tie pixels, %d id mismatches inside them" % (done, px, ties, tie_mis))
     assert ties <= 0.03 * px and tie_mis <= 0.02 * max(ties, 1) + 2, (ties, px, tie_mis)
+
+
+def test_children_outside_the_reference_bounds_of_their_group(ctx):
+    """Regression (found by tests/sweep_fuzz.py, 24 of 1 500 scenes): the reference's group bounds need not contain the
+    children (Bounds::from_points never looks at the first corner for `max`, bounds.rs:29-40; a rotated plane's infinite box
+    turns into garbage), and its bounds test is one against the whole line.  The product also drops children wholly BEHIND
+    the ray origin, which is only sound with a sphere around the children themselves (Compiler::geom_sphere), not around
+    those bounds.  Two minimal scenes (rotated groups with a plane inside): the product render, the reference-faithful
+    counting render and the oracle must agree."""
+    import glob
+    import ora
+    import rtx
+    import yaml_scene
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress_behind_*.yaml")))
+    assert len(files) >= 2
+    for f in files:
+        text = open(f).read()
+        depth = int(f.rsplit("depth", 1)[1].split(".")[0])
+        pw, pcs = rtx.load_yaml(text)
+        ow, ocs = yaml_scene.load(text, ora.API)
+        for dd in sorted({depth, 5}):
+            faithful = ctx.render(pw, pcs[0], dd, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
+            cpu = ora.render(ow, ocs[0], dd, threads=8)
+            parity.assert_parity(faithful, cpu, "%s depth %d" % (f, dd), max_tie_frac=0.25)
+            fast = ctx.render(pw, pcs[0], dd)
+            assert np.array_equal(fast["rgb"], faithful["rgb"]) and np.array_equal(fast["hit"], faithful["hit"]), (f, dd)
+            assert fast["stats"].rays == faithful["stats"].rays, (f, dd)
 
 
 def test_randomized_api_scene_graphs_parity(ctx):
