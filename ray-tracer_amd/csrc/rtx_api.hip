@@ -203,11 +203,28 @@ struct Compiler {
             j = cont ? (size_t)o.skip : j + 1;
         }
         if (ch.empty()) return;                                          // (an empty group has no hits; it is never visited for long)
-        const double c[3] = {(lo[0] + hi[0]) * 0.5, (lo[1] + hi[1]) * 0.5, (lo[2] + hi[2]) * 0.5};
-        double R = 0.0;
-        for (const float* s4 : ch) {
-            const double dx = s4[0] - c[0], dy = s4[1] - c[1], dz = s4[2] - c[2];
-            R = std::fmax(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s4[3]));
+        // enclosing sphere of the children's spheres: start at the centre of their joint box, then walk the centre towards the
+        // farthest child with shrinking steps (Badoiu-Clarkson), keeping the best centre seen
+        auto radius_at = [&](const double* c, int* far) {
+            double R = 0.0;
+            for (size_t i = 0; i < ch.size(); i++) {
+                const double dx = ch[i][0] - c[0], dy = ch[i][1] - c[1], dz = ch[i][2] - c[2];
+                const double ri = std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)ch[i][3]);
+                if (ri > R) { R = ri; if (far) *far = (int)i; }
+            }
+            return R;
+        };
+        double c[3] = {(lo[0] + hi[0]) * 0.5, (lo[1] + hi[1]) * 0.5, (lo[2] + hi[2]) * 0.5};
+        int far = 0;
+        double R = radius_at(c, &far), w[3] = {c[0], c[1], c[2]};
+        for (int it = 1; it <= 200 && ch.size() > 1; it++) {
+            // towards the farthest POINT of the farthest child: its centre pushed out by its radius
+            double dx = ch[far][0] - w[0], dy = ch[far][1] - w[1], dz = ch[far][2] - w[2];
+            const double dist = std::sqrt(dx * dx + dy * dy + dz * dz), rf = std::sqrt((double)ch[far][3]);
+            const double f = dist > 0.0 ? (dist + rf) / dist : 0.0;
+            w[0] += dx * f / (it + 1); w[1] += dy * f / (it + 1); w[2] += dz * f / (it + 1);
+            const double Rw = radius_at(w, &far);
+            if (Rw < R) { R = Rw; c[0] = w[0]; c[1] = w[1]; c[2] = w[2]; }
         }
         cull_sphere(d->node_inverse + (size_t)node * 16, c, R * 1.0001, out);
     }
