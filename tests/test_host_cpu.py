@@ -166,6 +166,26 @@ def test_png_writer_roundtrip(tmp_path):
     assert back.shape == img.shape and np.array_equal(back, img)
 
 
+def test_png_writer_large_image_is_one_valid_stream(tmp_path):
+    """write_png deflates row blocks on several threads and concatenates them (sync-flushed blocks + one final block, zlib
+    header and Adler-32 around them): a frame large enough for many blocks must decode to the same pixels with an
+    independent decoder, including ragged block boundaries."""
+    import time
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    h, w = 1031, 2049
+    img = (np.add.outer(np.arange(h), np.arange(w))[:, :, None] // np.array([3, 5, 7])).astype(np.uint8)   # smooth, like a render
+    img[::17, ::13] = rng.integers(0, 256, img[::17, ::13].shape, dtype=np.uint8)
+    p = str(tmp_path / "big.png")
+    t0 = time.perf_counter()
+    rtx.write_png(p, img)
+    dt = time.perf_counter() - t0
+    Image.MAX_IMAGE_PIXELS = None
+    back = np.asarray(Image.open(p))
+    assert back.shape == img.shape and np.array_equal(back, img)
+    print("write_png %dx%d: %.0f ms, %.1f MB" % (w, h, dt * 1e3, os.path.getsize(p) / 1e6))
+
+
 def test_cli_usage_message():
     out = subprocess.run([os.path.join(ROOT, "ray-tracer_amd", "rtx")], capture_output=True, text=True)
     assert "Need to provide filename of scene description as argument" in out.stdout     # main.rs:16
