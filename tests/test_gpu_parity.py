@@ -171,6 +171,13 @@ def test_full_size_properties_and_sampled_parity(ctx, name, w, h):
         a = sc.render(pc, 5)
         b = sc.render(pc, 5)
         assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"])          # deterministic
+        # (frames of this size go out in interleaved band sets on two lanes, rtx_render's default: the same as ONE launch)
+        ctx.set_option("host_sets", 1)
+        try:
+            one = sc.render(pc, 5)
+        finally:
+            ctx.set_option("host_sets", 0)
+        assert np.array_equal(a["rgb"], one["rgb"]) and np.array_equal(a["hit"], one["hit"]) and a["stats"].rays == one["stats"].rays
         c = sc.render(pc, 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
         assert np.array_equal(a["rgb"], c["rgb"]) and np.array_equal(a["hit"], c["hit"])
         st, ev = c["stats"], c["stats"].events()
