@@ -312,6 +312,11 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     int slotmap = 0;
     const int lane = threadIdx.x;
     int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
+#ifdef RTX_NO_LOCKSTEP
+    constexpr bool LOCKSTEP = false;                // (A/B builds: tools/lights_probe.py)
+#else
+    constexpr bool LOCKSTEP = !SPLIT && !PROBE;     // one kind of ray per iteration (see the top of the main loop)
+#endif
     constexpr int S = SPLIT ? RTX_SPLIT_BITS : 0;   // log2 waves per tile
     int sub = 0;                          // which part of the tile this wave renders
     if (!PROBE && rp.use_lists) {
@@ -479,17 +484,17 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // ---- one KIND of ray per iteration.  A lane alternates radiance and shadow traces, and the two kinds end in different
         // shading blocks (PreparedComputations / lighting + children), ~450 vector instructions each.  Lanes fall out of step
         // whenever a radiance ray misses or a shadow ray is skipped, and a wave whose lanes are at both kinds runs BOTH blocks
-        // in one iteration (27 % of S4's iterations did).  So when both kinds wait, only one of them is traced — the kinds take
-        // turns — and the lanes of the other sit this iteration out (as MODE_DONE: they keep their state and their ray in
-        // slot 0), which puts them back in step with the rest: S4 4.80 -> 4.55 ms.  (Letting the larger group go first was
-        // measured too: no gain — the lanes that sit out repeatedly become the tail.)  Not in SPLIT waves: their idle lanes
-        // are the helpers.
+        // in one iteration (27 % of S4's iterations did).  So when both kinds wait, only the SHADOW rays are traced and the
+        // radiance lanes sit this iteration out (as MODE_DONE: they keep their state and their ray in slot 0), which puts them
+        // back in step with the rest: S4 4.80 -> 4.55 ms.  Shadow rays first, because a hit is followed by one shadow ray
+        // per light: plain alternation gave the shadow lanes every other turn and lost 7 % on a three-light variant of S4
+        // (tools/lights_probe.py: 3.39 ms without any of this, 3.67 alternating, 3.30 shadow-first; 1.60 / 1.56 / 1.53 with
+        // one light).  Letting the LARGER group go first was measured too: no gain — the lanes that sit out repeatedly
+        // become the tail.  Not in SPLIT waves: their idle lanes are the helpers.
         unsigned long long hold_mask = 0;     // (a wave mask in scalar registers, not a per-lane flag: nothing more to keep live per lane)
-        if (!SPLIT && !PROBE) {
-            const bool wantR = mode == MODE_RADIANCE, wantS = mode == MODE_SHADOW;
-            const unsigned long long mR = __ballot(wantR), mS = __ballot(wantS);
-            phaseR = (mR != 0 && mS != 0) ? !phaseR : mR != 0;
-            const bool hold = (wantR && !phaseR) || (wantS && phaseR);
+        if (LOCKSTEP) {
+            phaseR = !__any(mode == MODE_SHADOW);
+            const bool hold = mode == MODE_RADIANCE && !phaseR;
             hold_mask = __ballot(hold);
             if (hold) mode = MODE_DONE;
         }
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         int cnt = 0;                      // CSG list length
         uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
         // (wave-uniform where the kinds take turns: the early-out tests and the container bookkeeping below become scalar branches)
-        const bool is_shadow = (!SPLIT && !PROBE) ? !phaseR : mode == MODE_SHADOW;
+        const bool is_shadow = LOCKSTEP ? !phaseR : mode == MODE_SHADOW;
 
         // The running state is ORDER-INDEPENDENT: ties in t resolve by op index (= the reference's visiting
         // order, which its stable sorts preserve), so shapes of one run may be fed in any order.
