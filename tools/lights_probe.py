@@ -8,8 +8,8 @@ os.environ.setdefault("RTX_HOST_SETS", "1")
 import rtx, scenes
 ctx = rtx.Context(0)
 base = scenes.make("S4", width=1920, height=1080)
-extra = ["- add: light\n  at: [9.0, 11.0, -8.0]\n  intensity: [0.4, 0.4, 0.4]\n\n", "- add: light\n  at: [0.0, 14.0, 3.0]\n  intensity: [0.3, 0.3, 0.3]\n\n"]
-for n in (1, 2, 3):
+extra = ["- add: light\n  at: [%.1f, %.1f, %.1f]\n  intensity: [0.3, 0.3, 0.3]\n\n" % p for p in ((9, 11, -8), (0, 14, 3), (-5, 9, 6), (6, 8, 7), (-9, 6, -3), (3, 13, -11), (1, 5, -14))]
+for n in [int(x) for x in os.environ.get('LIGHTS', '1,2,3').split(',')]:
     text = base.replace("- add: light", "".join(extra[:n - 1]) + "- add: light", 1)
     assert text.count("- add: light") == n
     world, cams = rtx.load_yaml(text)
