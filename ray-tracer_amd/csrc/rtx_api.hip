@@ -217,7 +217,7 @@ struct Compiler {
         double c[3] = {(lo[0] + hi[0]) * 0.5, (lo[1] + hi[1]) * 0.5, (lo[2] + hi[2]) * 0.5};
         int far = 0;
         double R = radius_at(c, &far), w[3] = {c[0], c[1], c[2]};
-        for (int it = 1; it <= 200 && ch.size() > 1; it++) {
+        for (int it = 1; it <= 48 && ch.size() > 1; it++) {
             // towards the farthest POINT of the farthest child: its centre pushed out by its radius
             double dx = ch[far][0] - w[0], dy = ch[far][1] - w[1], dz = ch[far][2] - w[2];
             const double dist = std::sqrt(dx * dx + dy * dy + dz * dz), rf = std::sqrt((double)ch[far][3]);
