@@ -154,6 +154,22 @@ def test_yaml_flow_and_comments():
     w1, _ = rtx.load_yaml(text)
     w2, _ = yaml_scene.load(text, rtx.API)
     assert rtx.serialize(w1) == rtx.serialize(w2)
+    # quoted scalars: escapes and doubled quotes are unescaped (the reader keeps views of the text for everything else),
+    # a quoted number is a string, a '#' inside quotes is no comment, a repeated key keeps its last value
+    text = ("- define: material\n  name: \"a \\\"b\\\" #1\"\n  color: [0.25, 0.5, 1]\n"
+            "- define: material\n  name: 'it''s'\n  extends: \"a \\\"b\\\" #1\"\n  ambient: 0.75\n  ambient: 0.5\n"
+            "- define: material\n  name: twelve\n  extends: 'it''s'\n  diffuse: 1e-1\n"
+            "- add: sphere\n  material: \"twelve\"\n"
+            "- {add: cube, material: 'it''s', transform: [{translate: [1, +2, -.5e1]}]}\n")
+    w1, _ = rtx.load_yaml(text)
+    w2, _ = yaml_scene.load(text, rtx.API)
+    assert rtx.serialize(w1) == rtx.serialize(w2)
+    # a quoted number is a String (yaml-rust types plain scalars only; the PyYAML-based restatement cannot tell them apart)
+    quoted = "- define: material\n  name: '12'\n  ambient: 0.5\n- add: sphere\n  material: \"12\"\n"
+    plain = "- define: material\n  name: m\n  ambient: 0.5\n- add: sphere\n  material: m\n"
+    assert rtx.serialize(rtx.load_yaml(quoted)[0]) == rtx.serialize(rtx.load_yaml(plain)[0])
+    with pytest.raises(rtx.RtxError):
+        rtx.load_yaml("- add: sphere\n  material: 12\n")          # an unquoted 12 is an Integer: as_str().unwrap() (yaml.rs:120)
 
 
 def test_png_writer_roundtrip(tmp_path):
