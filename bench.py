@@ -165,14 +165,35 @@ def main():
     stream = compute.cuda_stream
 
     # the product's communicator for the band gather (RCCL inside librtx_hip.so); torch.distributed only carries the 128-byte id,
-    # the barrier and the max-over-ranks of the timings
-    comm = None
+    # the barrier and the max-over-ranks of the timings.  Should the product's communicator not come up (all ranks decide
+    # together), the run falls back to torch.distributed's all-gather of the same compact bands and says so in the line,
+    # so that a scaling run still yields a labelled number; RTX_BENCH_NO_PRODUCT_COMM=1 rehearses that path.
+    comm, comm_error = None, None
+    torch_gather = False
     if (N > 1 or force_comm) and backend == "nccl":
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
         idt = torch.zeros(rtx.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
         if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(rtx.comm_unique_id()), dtype=torch.uint8))
+            try:
+                if os.environ.get("RTX_BENCH_NO_PRODUCT_COMM") == "1":
+                    raise rtx.RtxError(-1, "RTX_BENCH_NO_PRODUCT_COMM=1")
+                idt.copy_(torch.frombuffer(bytearray(rtx.comm_unique_id()), dtype=torch.uint8))
+            except rtx.RtxError as e:
+                ok.zero_(); comm_error = str(e)
         dist.broadcast(idt, 0)
-        comm = rtx.Comm(ctx, bytes(idt.cpu().numpy().tobytes()), rank, N)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) == 1:
+            try:
+                comm = rtx.Comm(ctx, bytes(idt.cpu().numpy().tobytes()), rank, N)
+            except rtx.RtxError as e:
+                ok.zero_(); comm_error = str(e)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0 and comm is not None:
+                comm.close(); comm = None
+        if comm is None:
+            torch_gather = True
+            print("bench.py: the product's communicator did not come up (%s); gathering through torch.distributed" % comm_error,
+                  file=sys.stderr, flush=True)
 
     def measure(workload, width, height, steps, warmup):
         """-> dict of this workload's numbers (on every rank; only rank 0 prints)"""
@@ -186,7 +207,12 @@ def main():
         rows_pad = rtx.LIB.rtx_band_rows_padded(height, N)
         local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
         frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=dev) for _ in range(4)] if (N > 1 or comm is not None) else None
-        gathered_host = torch.zeros((N, rows_pad * width * 3), dtype=torch.uint8) if (N > 1 and comm is None) else None
+        gathered_host = torch.zeros((N, rows_pad * width * 3), dtype=torch.uint8) if (N > 1 and comm is None and not torch_gather) else None
+        if torch_gather:     # fallback gather: frame row y is row (y // 8 // N) * 8 + y % 8 of rank (y // 8) % N's compact buffer
+            y = torch.arange(height, device=dev)
+            src_row = ((y // 8) % N) * rows_pad + (y // 8 // N) * 8 + y % 8
+            gathered_dev = torch.zeros((N * rows_pad, width * 3), dtype=torch.uint8, device=dev)
+            frame_dev = torch.zeros((height, width * 3), dtype=torch.uint8, device=dev)
 
         # exact ray and event counts of this rank's share (untimed); a device-side overflow would raise here.  Two passes:
         # the reference-faithful one (no shadow early-out, no skipped shadow rays, loose CSG spheres: its event counts are the
@@ -210,6 +236,10 @@ def main():
         def step(k):
             if comm is not None:
                 comm.render_gathered(scene, cam, frames[k & 3].data_ptr(), 0, 5, 0, stream)
+            elif torch_gather:
+                scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
+                dist.all_gather_into_tensor(gathered_dev.view(-1), local)
+                torch.index_select(gathered_dev, 0, src_row, out=frame_dev)
             else:
                 scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
                 if N > 1:      # gloo rehearsal: host gather + the C ABI's host de-interleave
@@ -240,6 +270,13 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         ctx.poll(wait=True)                           # an overflow in any timed frame is an error, not a number
+        if os.environ.get("RTX_BENCH_CHECK") == "1" and (comm is not None or torch_gather):
+            # rehearsal aid: the gathered frame of the last timed step must equal this GPU's own render of the whole frame
+            whole = torch.zeros(height * width * 3, dtype=torch.uint8, device=dev)
+            scene.render_device(cam, whole.data_ptr(), 0, 5, (0, 1), 0, stream, True)
+            got = frame_dev.view(-1) if torch_gather else frames[(steps - 1) & 3]
+            assert torch.equal(got, whole), "gathered frame differs from the single-GPU frame"
+            print("bench.py: gathered frame == single-GPU frame (rank %d)" % rank, file=sys.stderr, flush=True)
         if comm is None and N == 1:
             kern = sum(a.elapsed_time(b) for a, b in ev) / steps
         else:
@@ -297,7 +334,9 @@ def main():
     if rank == 0:
         gather = ("row-interleaved 8-row bands x%d + one ncclAllGather per frame inside the product (rtx_render_gathered), "
                   "up to three frames in flight on alternating render lanes" % N) if comm is not None else \
-                 ("row-interleaved 8-row bands x%d, gloo REHEARSAL gather through host memory" % N if N > 1 else "1 GPU")
+                 ("row-interleaved 8-row bands x%d, FALLBACK gather through torch.distributed (the product's communicator did not "
+                  "come up: %s)" % (N, comm_error) if torch_gather else
+                  "row-interleaved 8-row bands x%d, gloo REHEARSAL gather through host memory" % N if N > 1 else "1 GPU")
         m["roofline"]["note"] = ("achieved/frac are ALGORITHMIC (SURVEY.md 8d): reference-defined node visits and shading events (counted by a "
                                  "pass in the reference-faithful mode: is_shadowed visits everything, as world.rs:196-206 does) x the survey's "
                                  "flop constants / kernel time; the conservative pre-tests answer most node visits without the f64 arithmetic, so "
@@ -331,7 +370,7 @@ def main():
     if comm is not None:
         comm.close()
     ctx.close()
-    if N > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
