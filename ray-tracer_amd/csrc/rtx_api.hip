@@ -876,6 +876,23 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 HIPCHK(ctx, hipMalloc((void**)&lane->d_lists, (size_t)RTX_TILE_CLASSES * n_tiles * sizeof(int32_t)));
                 lane->tile_cap = n_tiles;
             }
+#ifdef RTX_EXP_ORDER
+            // experiment build only (tools/order_probe.py): the tile lists come from a file instead of the probe launch
+            static bool exp_loaded = false;
+            const char* exp_file = std::getenv("RTX_EXP_ORDER_FILE");
+            if (exp_file && !exp_loaded) {
+                std::vector<int32_t> data((size_t)RTX_TILE_CLASSES + (size_t)RTX_TILE_CLASSES * n_tiles, 0);
+                FILE* f = std::fopen(exp_file, "rb");
+                if (!f || std::fread(data.data(), sizeof(int32_t), data.size(), f) != data.size()) return fail(ctx, RTX_E_INVALID, "RTX_EXP_ORDER_FILE unreadable");
+                std::fclose(f);
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                HIPCHK(ctx, hipMemcpy(lane->d_tile_counts, data.data(), RTX_TILE_CLASSES * sizeof(int32_t), hipMemcpyHostToDevice));
+                HIPCHK(ctx, hipMemcpy(lane->d_lists, data.data() + RTX_TILE_CLASSES, (size_t)RTX_TILE_CLASSES * n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
+                exp_loaded = true;
+            }
+            if (exp_file) { rp.use_lists = 1; rp.tile_lists = lane->d_lists; rp.tile_counts = lane->d_tile_counts; }
+            else {
+#endif
             HIPCHK(ctx, hipMemsetAsync(lane->d_tile_counts, 0, RTX_TILE_CLASSES * sizeof(int32_t), st));
             RenderParams pp = rp;
             {
@@ -905,6 +922,9 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 rp.split_guard = (int32_t)(g > 0x3fffffff ? 0x3fffffff : g);
                 if (ctx->opt.debug == 2) rp.split_guard = 1;        // test hook: every split wave gives up (sticky-error test)
             }
+#ifdef RTX_EXP_ORDER
+            }
+#endif
         }
     }
     if (rp.split_cap > 0) {

@@ -1583,6 +1583,14 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         }
     }
 #endif
+#ifdef RTX_PIXEL_COST
+    // diagnostic build (tools/pixel_cost.py): the hit-id plane receives every pixel's traced rays instead of its hit id
+    if (hit_out && !SPLIT) {
+        const int px = tx * RTX_TILE + (pl & 7), py = band * RTX_TILE + (pl >> 3);
+        const int row = rp.compact ? (bl * RTX_TILE + (pl >> 3)) : py;
+        if (px < cam.hsize && py < cam.vsize) hit_out[(size_t)row * cam.hsize + px] = (int)(n_radiance + n_shadow - n_skipped);
+    }
+#endif
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow), t3 = wave_sum(n_skipped);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)

@@ -1,4 +1,4 @@
-"""One-off randomized parity sweep (not collected by pytest): python tests/sweep_fuzz.py on a GPU box.
+"""One-off randomized parity sweep (not collected by pytest): python tests/sweep_fuzz.py [n_seeds [first_seed]] on a GPU box.
 Test infrastructure: compares the HIP path with the oracle on generated scene files (tests/fuzz_scenes.py)."""
 import sys, os
 ROOT = os.getcwd()
@@ -7,7 +7,7 @@ import numpy as np, fuzz_scenes, rtx, yaml_scene, ora, parity, rtapi
 ctx = rtx.Context(0)
 bad = skipped = ties = 0
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng((int(sys.argv[2]) if len(sys.argv) > 2 else 1000) + seed)
     for i in range(150):
         w, h = int(rng.integers(8, 120)), int(rng.integers(8, 90))
         text = fuzz_scenes.make(rng, w, h)
