@@ -153,7 +153,9 @@ int  rtx_render(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rt
 /* Same, but the outputs are DEVICE pointers on the context's device and the launch is queued on
  * `stream` (a hipStream_t, NULL = the context's own stream) without a host copy; used when the
  * caller gathers bands itself.  Synchronises only if stats != NULL; without stats a device-side overflow is
- * reported through the sticky error of rtx_ctx_poll() below. */
+ * reported through the sticky error of rtx_ctx_poll() below.  Everything the caller can observe (image, ids, counters)
+ * is ordered on `stream`; a frame queued while `stream` is still busy may have its tile-order probe (which reads only the
+ * scene and the camera) run on an internal stream beside the work before it (option "probe_ahead"). */
 int  rtx_render_device(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_depth, rtx_bands bands,
                        uint32_t flags, void* d_rgb, void* d_hit, void* stream, rtx_stats* stats);
 
@@ -165,8 +167,9 @@ int  rtx_render_device(rtx_ctx*, const rtx_scene*, const rtx_camera*, int max_de
 int  rtx_ctx_poll(rtx_ctx*, int wait);
 
 /* Scheduling knobs of a context (they never change an image).  Defaults come from the environment
- * ONCE, at rtx_init (RTX_LPT, RTX_TILE_MUL, RTX_PROBE_DEPTH, RTX_SPLIT, RTX_SPLIT_CLASS); names here: "lpt", "tile_mul",
- * "probe_depth", "split", "split_class"; value -1 = the per-scene default for "lpt" and "split".
+ * ONCE, at rtx_init (RTX_LPT, RTX_TILE_MUL, RTX_PROBE_DEPTH, RTX_SPLIT, RTX_SPLIT_CLASS, RTX_PROBE_AHEAD, RTX_STREAM_LPT,
+ * RTX_HOST_SETS, RTX_PIPELINE); names here: "lpt", "tile_mul", "probe_depth", "split", "split_class", "probe_ahead",
+ * "stream_lpt", "host_sets", "pipeline"; value -1 = the default for "lpt", "split", "probe_ahead" and "stream_lpt".
  * No counterpart in the reference (it has no scheduler). */
 int  rtx_set_option(rtx_ctx*, const char* name, int value);
 

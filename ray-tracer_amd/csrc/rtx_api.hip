@@ -560,6 +560,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.pipeline = env_int("RTX_PIPELINE", 3);
     c->opt.host_sets = env_int("RTX_HOST_SETS", 0);
     c->opt.stream_lpt = env_int("RTX_STREAM_LPT", -1);
+    c->opt.probe_ahead = env_int("RTX_PROBE_AHEAD", -1);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -609,6 +610,7 @@ void rtx_shutdown(rtx_ctx* c) {
     for (int l = 0; l < rtx_ctx::kLanes; l++) {
         if (c->lanes[l].d_lists) (void)hipFree(c->lanes[l].d_lists);
         if (c->lanes[l].d_tile_counts) (void)hipFree(c->lanes[l].d_tile_counts);
+        c->lanes[l].release_ahead();
         if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
         if (c->lanes[l].side) (void)hipStreamDestroy(c->lanes[l].side);
         if (c->lanes[l].ev_fork) (void)hipEventDestroy(c->lanes[l].ev_fork);
@@ -635,6 +637,7 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "pipeline") c->opt.pipeline = value;
     else if (n == "host_sets") c->opt.host_sets = value;
     else if (n == "stream_lpt") c->opt.stream_lpt = value;
+    else if (n == "probe_ahead") c->opt.probe_ahead = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
 }
@@ -856,6 +859,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     rp.compact = (flags & RTX_F_BANDS_COMPACT) ? 1 : 0;
     rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
 
+    int ahead_set = -1;                           // list set whose "frame launch done" event this render records (probe ahead, below)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(d_counters, 0, kCounterWords * sizeof(unsigned long long), st));
     if (ev_begin) HIPCHK(ctx, hipEventRecord(ev_begin, st));
@@ -893,7 +897,47 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             if (exp_file) { rp.use_lists = 1; rp.tile_lists = lane->d_lists; rp.tile_counts = lane->d_tile_counts; }
             else {
 #endif
-            HIPCHK(ctx, hipMemsetAsync(lane->d_tile_counts, 0, RTX_TILE_CLASSES * sizeof(int32_t), st));
+            // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
+            // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
+            // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
+            const bool split = !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES) && lane->side;
+            // PROBE AHEAD.  The probe is a chain of dependent rays on a few thousand waves: ~0.1 ms during which the chip is
+            // nearly empty (2.5 % of a 4K frame).  When the caller's stream still holds work — frames are being queued one
+            // behind the other — the probe goes to the lane's side stream and into the list set the frame before it is NOT
+            // reading, so it runs beside that frame and this frame's launch finds its lists ready.  Stream order of everything
+            // the caller can see (image, counters) is unchanged; if the two streams share a hardware queue the probe simply
+            // runs where it used to.  A frame queued on an idle stream keeps the in-stream probe (no event hop in its latency).
+            // (Callers that overlap whole frames themselves — the render lanes of rtx_render_gathered and rtx_render's band sets,
+            // which pass RTX_F_INTERNAL_NO_SPLIT, and the lanes of rtx_render_batch — gain nothing from it: measured 0 to -4 %.)
+            bool ahead = !split && !(flags & (RTX_F_INTERNAL_NO_SPLIT | RTX_F_INTERNAL_NO_AHEAD)) && may_allocate && lane->side && ctx->opt.probe_ahead != 0;
+            if (ahead && ctx->opt.probe_ahead < 0) ahead = hipStreamQuery(st) == hipErrorNotReady;
+            (void)hipGetLastError();
+            int32_t* lists = lane->d_lists; int32_t* counts = lane->d_tile_counts;
+            hipStream_t pst = st;
+            int set = 0;
+            if (ahead) {
+                set = lane->flip; lane->flip ^= 1;
+                for (int i = 0; i < 2; i++) {
+                    if (!lane->ev_probe[i]) HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_probe[i], hipEventDisableTiming));
+                    if (!lane->ev_main[i]) HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_main[i], hipEventDisableTiming));
+                }
+                if (set == 1) {
+                    if (lane->tile_cap_b < (size_t)n_tiles) {
+                        if (lane->d_lists_b) (void)hipFree(lane->d_lists_b);
+                        lane->d_lists_b = nullptr; lane->tile_cap_b = 0;
+                        HIPCHK(ctx, hipMalloc((void**)&lane->d_lists_b, (size_t)RTX_TILE_CLASSES * n_tiles * sizeof(int32_t)));
+                        lane->tile_cap_b = n_tiles;
+                    }
+                    lists = lane->d_lists_b; counts = lane->d_tile_counts + 32;
+                }
+                pst = lane->side;
+                if (lane->main_recorded[set]) HIPCHK(ctx, hipStreamWaitEvent(pst, lane->ev_main[set], 0));
+            } else {
+                // the in-stream probe refills set 0: a frame launch that still reads it is ahead of us on `st` only if the caller kept
+                // to one stream; an ahead-frame's launch on another stream is ordered by its event
+                if (lane->main_recorded[0] && lane->ev_main[0]) HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_main[0], 0));
+            }
+            HIPCHK(ctx, hipMemsetAsync(counts, 0, RTX_TILE_CLASSES * sizeof(int32_t), pst));
             RenderParams pp = rp;
             {
                 const long long n_super = (long long)((rp.tiles_x + 7) / 8) * ((rp.n_bands_local + 7) / 8);
@@ -905,14 +949,15 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             }
             pp.probe = 1; pp.max_depth = ctx->opt.probe_depth;   // (1, 2, 3 measured: 2 is best)
             if (pp.max_depth < 0) pp.max_depth = 0;
-            if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lane->d_lists; pp.tile_counts = lane->d_tile_counts;
-            HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, st));
-            rp.use_lists = 1; rp.tile_lists = lane->d_lists; rp.tile_counts = lane->d_tile_counts;
-            // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
-            // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
-            // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
-            const bool split = !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES);
-            if (split && lane->side) {
+            if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lists; pp.tile_counts = counts;
+            HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, pst));
+            rp.use_lists = 1; rp.tile_lists = lists; rp.tile_counts = counts;
+            if (ahead) {
+                HIPCHK(ctx, hipEventRecord(lane->ev_probe[set], pst));
+                HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_probe[set], 0));
+            }
+            ahead_set = (ahead || lane->ev_main[0]) ? set : -1;
+            if (split) {
                 rp.split_cap = n_tiles / 4 > 0 ? n_tiles / 4 : 1;
                 rp.split_min_class = ctx->opt.split_class;
                 if (rp.split_min_class < 1) rp.split_min_class = 1;
@@ -940,6 +985,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &rp, (uint8_t*)d_rgb, (int32_t*)d_hit, d_counters,
                                        (flags & RTX_F_COUNT_EVENTS) ? 1 : 0, st));
     if (rp.split_cap > 0) HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_join, 0));
+    if (ahead_set >= 0) { HIPCHK(ctx, hipEventRecord(lane->ev_main[ahead_set], st)); lane->main_recorded[ahead_set] = true; }
     if (ev_end) HIPCHK(ctx, hipEventRecord(ev_end, st));
     ctx->last_stream = st;
     return RTX_OK;
@@ -1322,7 +1368,7 @@ int rtx_render_batch(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam
         rtx_ctx::Lane& ln = ctx->lanes[i % n_lanes];
         const size_t npx = (size_t)cams[i].hsize * cams[i].vsize;
         const bool want_hit = hit && hit[i];
-        rc = enqueue_render(ctx, scene, &cams[i], max_depth, rtx_bands{0, 1}, flags, ctx->d_rgb + off_rgb[i],
+        rc = enqueue_render(ctx, scene, &cams[i], max_depth, rtx_bands{0, 1}, flags | RTX_F_INTERNAL_NO_AHEAD, ctx->d_rgb + off_rgb[i],
                             want_hit ? (void*)((uint8_t*)ctx->d_hit + off_hit[i]) : nullptr, ln.stream, &ln,
                             ctx->d_batch_counters + (size_t)i * kCounterWords,
                             stats ? ev[2 * i] : nullptr, stats ? ev[2 * i + 1] : nullptr);

@@ -18,6 +18,8 @@ struct rtx_opts {
     int split = -1;          // split tiles: -1 = default (short dispatches), 0 / 1 = forced
     int split_class = 7;     // tiles of this cost class and above are split
     int debug = 0;
+    int probe_ahead = -1;    // the probe of a frame queued behind a running one runs beside it, on the lane's side stream: -1 = when the
+                             // caller's stream is busy, 0 = never, 1 = always
     int stream_lpt = -1;     // streaming callers of rtx_render_gathered keep the tile-order probe: -1 = by dispatch length, 0 / 1 = forced
     int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
     int pipeline = 3;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
@@ -36,8 +38,19 @@ struct rtx_ctx {
     // scheduling state of one stream: tile class lists (grown on demand) and their fill counts.  lanes[0] runs
     // on `stream`; lanes 1.. have streams of their own and are created by the first rtx_render_batch.
     // side/ev_fork/ev_join: the SPLIT launch of a frame runs on `side`, beside the main launch
+    // probe ahead (rtx_api.hip, enqueue_render): the tile-order probe of a frame runs on `side` into one of TWO list sets
+    // (d_lists / d_lists_b, counts at d_tile_counts + 0 / + 32), so it can run beside the frame before it; ev_probe[s] = the
+    // probe that filled set s is done, ev_main[s] = the frame launch that read set s is done (the set may be refilled)
     struct Lane { hipStream_t stream = nullptr; int32_t* d_lists = nullptr; int32_t* d_tile_counts = nullptr; size_t tile_cap = 0;
-                  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+                  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+                  int32_t* d_lists_b = nullptr; size_t tile_cap_b = 0; hipEvent_t ev_probe[2] = {nullptr, nullptr}, ev_main[2] = {nullptr, nullptr};
+                  bool main_recorded[2] = {false, false}; int flip = 0;
+                  void release_ahead() {
+                      if (d_lists_b) (void)hipFree(d_lists_b);
+                      for (int i = 0; i < 2; i++) { if (ev_probe[i]) (void)hipEventDestroy(ev_probe[i]); if (ev_main[i]) (void)hipEventDestroy(ev_main[i]); }
+                      d_lists_b = nullptr; tile_cap_b = 0; ev_probe[0] = ev_probe[1] = ev_main[0] = ev_main[1] = nullptr;
+                      main_recorded[0] = main_recorded[1] = false;
+                  } };
     static constexpr int kLanes = 4;
     Lane lanes[kLanes];
     uint8_t* h_stage = nullptr; size_t stage_cap = 0;                        // pinned staging of a batch's images
@@ -91,6 +104,8 @@ bool rtx_streams_overlap(const std::vector<hipStream_t>& streams);
 constexpr uint32_t RTX_F_INTERNAL_NO_SPLIT = 1u << 16;
 // ... and: no tile-order probe either (plain permuted order)
 constexpr uint32_t RTX_F_INTERNAL_NO_LPT = 1u << 17;
+// ... and: the probe stays on the render's own stream (callers that put whole frames side by side themselves)
+constexpr uint32_t RTX_F_INTERNAL_NO_AHEAD = 1u << 18;
 // RTX_E_CAPACITY (and the message) if an earlier asynchronous render reported an overflow that nobody collected yet
 int rtx_check_sticky(rtx_ctx* ctx);
 

@@ -419,6 +419,7 @@ void rtx_comm_destroy(rtx_comm* c) {
         if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
         if (ln.d_lists) (void)hipFree(ln.d_lists);
         if (ln.d_tile_counts) (void)hipFree(ln.d_tile_counts);
+        ln.release_ahead();
         if (c->d_counters[b]) (void)hipFree(c->d_counters[b]);
     }
     if (c->gstream) (void)hipStreamDestroy(c->gstream);

@@ -157,7 +157,7 @@ class Context:
         return Scene(self, world)
 
     def set_option(self, name, value):
-        """rtx_set_option: scheduling knobs ("lpt", "split", "split_class", "tile_mul", "probe_depth"); -1 = default."""
+        """rtx_set_option: scheduling knobs ("lpt", "split", "split_class", "tile_mul", "probe_depth", "probe_ahead", ...); -1 = default."""
         self._check(LIB.rtx_set_option(self.h, name.encode(), int(value)))
 
     def options(self, **kv):

@@ -586,6 +586,50 @@ def test_render_device_writes_device_buffers_on_the_callers_stream(ctx):
         hip.lib.hipStreamDestroy(st)
 
 
+def test_probe_ahead_of_queued_frames_does_not_change_them(ctx):
+    """A frame queued behind a running one gets its tile-order probe on the lane's side stream, into the list set the running
+    frame is not reading (rtx_api.hip: probe ahead).  Eight frames of alternating cameras and SIZES queued back to back on
+    one stream (so a list set that belonged to the wrong frame would leave tiles unrendered or render them twice), forced
+    on (option probe_ahead = 1) and in the automatic mode, must equal the frames rendered one at a time; ray counts through
+    the asynchronous counters are checked by the last, synchronous frame."""
+    import ctypes as C
+    import rtx
+    hip = _Hip()
+    cams, wants, worlds = [], [], []
+    st = C.c_void_p()
+    assert hip.lib.hipStreamCreate(C.byref(st)) == 0
+    bufs = []
+    ctx.options(lpt=1, split=0)
+    try:
+        pw, pc = rtx.load_yaml(parity.scene_text("S4", 333, 171))
+        sc = ctx.scene(pw)
+        for w, h in ((333, 171), (200, 301), (640, 96)):
+            _, c = rtx.load_yaml(parity.scene_text("S4", w, h))
+            cams.append(c[0]); wants.append(sc.render(c[0], 5))
+        for mode in (1, -1):
+            ctx.set_option("probe_ahead", mode)
+            outs = []
+            for k in range(8):
+                cam = cams[k % 3]
+                b = hip.malloc(cam.vsize * cam.hsize * 3, 0x55); bufs.append(b)
+                assert sc.render_device(cam, b.value, 0, 5, stream=st.value) is None
+                outs.append((k % 3, b))
+            stats = sc.render_device(cams[0], outs[0][1].value, 0, 5, stream=st.value, stats=True)
+            assert stats.rays == wants[0]["stats"].rays
+            assert hip.lib.hipStreamSynchronize(st) == 0
+            for i, b in outs:
+                cam = cams[i]
+                got = hip.to_host(b, cam.vsize * cam.hsize * 3, np.uint8).reshape(cam.vsize, cam.hsize, 3)
+                assert np.array_equal(got, wants[i]["rgb"]), (mode, i)
+        sc.close()
+    finally:
+        ctx.options(lpt=-1, split=-1)
+        ctx.set_option("probe_ahead", -1)
+        for b in bufs:
+            hip.lib.hipFree(b)
+        hip.lib.hipStreamDestroy(st)
+
+
 def test_host_render_in_band_sets_equals_one_launch(ctx):
     """rtx_render of a whole frame into host buffers renders large frames as 2..8 interleaved band sets on two lanes and copies
     each set out while the next ones render (option host_sets; 0 = by frame size).  Forced here on small ragged frames:
