@@ -1246,9 +1246,13 @@ int rtx_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int 
         // how many sets: more sets hide more of the copy behind the render (what is left over is the last set's), but each set
         // is a shorter dispatch with a tail and a probe of its own; scenes whose pixel costs span orders of magnitude
         // (has_branching: the tail-bound ones) want few.  Measured with tools/host_latency.py
+        // The FIRST whole-frame render of a context takes the plain path below: the band sets need pinned staging for the frame
+        // and two calibrated render lanes (S5 8K: +22 ms, S3 4K: +11 ms of set-up against 9 / 2 ms saved per frame), which a
+        // process that renders one frame (the CLI) would pay for nothing; a second render says that more are coming.
+        const bool cold = ctx->host_renders++ == 0;
         long long C = 1;
         if (ctx->opt.host_sets > 0) C = ctx->opt.host_sets;
-        else if (n_tiles >= 8000) {
+        else if (n_tiles >= 8000 && !cold) {
             C = scene->dev.has_branching ? n_tiles / 32000 : n_tiles / 8000;
             const long long hi = scene->dev.has_branching ? 4 : 8;
             C = C < 2 ? 2 : (C > hi ? hi : C);

@@ -62,6 +62,7 @@ struct rtx_ctx {
     // overflow count's "non-zero" there); read by the next render call / rtx_ctx_poll without touching the stream
     volatile unsigned long long* h_sticky = nullptr;
     unsigned long long* d_sticky = nullptr;                                  // the same word as the device addresses it
+    long long host_renders = 0;                                              // whole-frame rtx_render calls so far (the first one sets nothing up: rtx_api.hip)
     hipStream_t last_stream = nullptr;                                       // stream of the last queued render (rtx_ctx_poll waits on it)
     // the library's no-alloc scratch (rtx_api.hip: `scratch`): this device's copy of the file-scope array
     unsigned char* d_scratch = nullptr;
