@@ -52,6 +52,8 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
 #define RTX_NOALLOC_SCRATCH_BYTES (RTX_NOALLOC_COUNTER_BYTES + RTX_NOALLOC_COUNTS_BYTES + RTX_NOALLOC_LISTS_BYTES)
 static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];
 
+int rtx_earlier_overflow(rtx_ctx* ctx);
+
 namespace {
 
 int fail(rtx_ctx* c, int code, const std::string& msg) { return rtx_fail(c, code, msg); }
@@ -591,6 +593,10 @@ int rtx_init(int device, rtx_ctx** out) {
     c->noalloc_lane.d_lists = (int32_t*)(c->d_scratch + RTX_NOALLOC_COUNTER_BYTES + RTX_NOALLOC_COUNTS_BYTES);
     c->noalloc_lane.tile_cap = RTX_NOALLOC_MAX_TILES;
     c->noalloc_lane.side = l0.side; c->noalloc_lane.ev_fork = l0.ev_fork; c->noalloc_lane.ev_join = l0.ev_join;
+    if (rtx_lane_events(c, &l0) != RTX_OK || rtx_lane_events(c, &c->noalloc_lane) != RTX_OK) {
+        rtx_shutdown(c);
+        return RTX_E_DEVICE;
+    }
     *out = c;
     return RTX_OK;
 }
@@ -598,7 +604,7 @@ int rtx_init(int device, rtx_ctx** out) {
 void rtx_shutdown(rtx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+    (void)hipDeviceSynchronize();                 // renders may still be in flight on any of the streams used so far
     // scenes the caller has not destroyed yet: their device memory goes now, the handles stay valid for
     // rtx_scene_destroy (which then only frees the host struct)
     for (rtx_scene* s : c->scenes) { release_scene_memory(s); s->ctx = nullptr; }
@@ -611,6 +617,7 @@ void rtx_shutdown(rtx_ctx* c) {
         if (c->lanes[l].d_lists) (void)hipFree(c->lanes[l].d_lists);
         if (c->lanes[l].d_tile_counts) (void)hipFree(c->lanes[l].d_tile_counts);
         c->lanes[l].release_ahead();
+        if (l == 0) c->noalloc_lane.release_ahead();
         if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
         if (c->lanes[l].side) (void)hipStreamDestroy(c->lanes[l].side);
         if (c->lanes[l].ev_fork) (void)hipEventDestroy(c->lanes[l].ev_fork);
@@ -644,9 +651,11 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
 
 int rtx_ctx_poll(rtx_ctx* c, int wait) {
     if (!c) return RTX_E_INVALID;
-    if (wait && c->last_stream) {
+    if (wait) {
+        // renders may be in flight on several streams (caller streams used in turn, the render lanes of a communicator, band
+        // sets): wait for the device, not for the stream of the last call
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipStreamSynchronize(c->last_stream));
+        HIPCHK(c, hipDeviceSynchronize());
     }
     const int rc = rtx_check_sticky(c);
     *c->h_sticky = 0;
@@ -782,7 +791,7 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->ctx) {
         // (renders queued asynchronously may still read the scene: wait for the last one before freeing)
         (void)hipSetDevice(s->device);
-        if (s->ctx->last_stream) (void)hipStreamSynchronize(s->ctx->last_stream);
+        (void)hipDeviceSynchronize();
         auto& v = s->ctx->scenes;
         v.erase(std::remove(v.begin(), v.end(), s), v.end());
         release_scene_memory(s);
@@ -859,7 +868,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     rp.compact = (flags & RTX_F_BANDS_COMPACT) ? 1 : 0;
     rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
 
-    int ahead_set = -1;                           // list set whose "frame launch done" event this render records (probe ahead, below)
+    int ahead_set = -1;                           // list set this frame's launches read: its "launch done" event is recorded at the end
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(d_counters, 0, kCounterWords * sizeof(unsigned long long), st));
     if (ev_begin) HIPCHK(ctx, hipEventRecord(ev_begin, st));
@@ -915,12 +924,10 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             int32_t* lists = lane->d_lists; int32_t* counts = lane->d_tile_counts;
             hipStream_t pst = st;
             int set = 0;
+            if (!lane->ev_main[0] || !lane->ev_main[1] || !lane->ev_probe[0] || !lane->ev_probe[1])
+                return fail(ctx, RTX_E_INVALID, "render lane without its list-set events (rtx_lane_events)");
             if (ahead) {
                 set = lane->flip; lane->flip ^= 1;
-                for (int i = 0; i < 2; i++) {
-                    if (!lane->ev_probe[i]) HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_probe[i], hipEventDisableTiming));
-                    if (!lane->ev_main[i]) HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_main[i], hipEventDisableTiming));
-                }
                 if (set == 1) {
                     if (lane->tile_cap_b < (size_t)n_tiles) {
                         if (lane->d_lists_b) (void)hipFree(lane->d_lists_b);
@@ -931,12 +938,11 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                     lists = lane->d_lists_b; counts = lane->d_tile_counts + 32;
                 }
                 pst = lane->side;
-                if (lane->main_recorded[set]) HIPCHK(ctx, hipStreamWaitEvent(pst, lane->ev_main[set], 0));
-            } else {
-                // the in-stream probe refills set 0: a frame launch that still reads it is ahead of us on `st` only if the caller kept
-                // to one stream; an ahead-frame's launch on another stream is ordered by its event
-                if (lane->main_recorded[0] && lane->ev_main[0]) HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_main[0], 0));
             }
+            // The probe REFILLS list set `set` (counts zeroed, lists rewritten): it must come after the last frame launch that
+            // READ the set, whichever stream that launch was queued on and whichever kind of frame it belonged to (in-stream
+            // probe, split, probe ahead).  Every such launch records ev_main[set] (below); a set nobody has read yet has none.
+            if (lane->main_recorded[set]) HIPCHK(ctx, hipStreamWaitEvent(pst, lane->ev_main[set], 0));
             HIPCHK(ctx, hipMemsetAsync(counts, 0, RTX_TILE_CLASSES * sizeof(int32_t), pst));
             RenderParams pp = rp;
             {
@@ -956,7 +962,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 HIPCHK(ctx, hipEventRecord(lane->ev_probe[set], pst));
                 HIPCHK(ctx, hipStreamWaitEvent(st, lane->ev_probe[set], 0));
             }
-            ahead_set = (ahead || lane->ev_main[0]) ? set : -1;
+            ahead_set = set;
             if (split) {
                 rp.split_cap = n_tiles / 4 > 0 ? n_tiles / 4 : 1;
                 rp.split_min_class = ctx->opt.split_class;
@@ -1025,6 +1031,8 @@ int ensure_lanes(rtx_ctx* ctx, int n) {
             HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
             HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
         }
+        const int erc = rtx_lane_events(ctx, &ln);
+        if (erc != RTX_OK) return erc;
     }
     return RTX_OK;
 }
@@ -1156,7 +1164,10 @@ int render_chunked(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
         if (stats) *stats = sum;
     }
     drop_events();
-    *ctx->h_sticky = 0;                               // this call reports its own overflow through the return code
+    // this call reports its own overflow through the return code; a raised word with clean counters is an earlier render's
+    const bool raised = *ctx->h_sticky != 0;
+    *ctx->h_sticky = 0;
+    if (rc == RTX_OK && raised) rc = rtx_earlier_overflow(ctx);
     return rc;
 }
 
@@ -1183,10 +1194,22 @@ bool rtx_streams_overlap(const std::vector<hipStream_t>& ss) {
     return ok && best < 160.0;
 }
 
+int rtx_lane_events(rtx_ctx* ctx, rtx_ctx::Lane* lane) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < 2; i++) {
+        if (!lane->ev_probe[i]) HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_probe[i], hipEventDisableTiming));
+        if (!lane->ev_main[i]) HIPCHK(ctx, hipEventCreateWithFlags(&lane->ev_main[i], hipEventDisableTiming));
+    }
+    return RTX_OK;
+}
+
+int rtx_earlier_overflow(rtx_ctx* ctx) {
+    return rtx_fail(ctx, RTX_E_CAPACITY, "an earlier asynchronous render overflowed a bounded list or tripped the split guard "
+                                         "(its image is incomplete); rtx_ctx_poll() clears the condition");
+}
+
 int rtx_check_sticky(rtx_ctx* ctx) {
-    if (ctx->h_sticky && *ctx->h_sticky != 0)
-        return rtx_fail(ctx, RTX_E_CAPACITY, "an earlier asynchronous render overflowed a bounded list or tripped the split guard "
-                                             "(its image is incomplete); rtx_ctx_poll() clears the condition");
+    if (ctx->h_sticky && *ctx->h_sticky != 0) return rtx_earlier_overflow(ctx);
     return RTX_OK;
 }
 
@@ -1211,8 +1234,14 @@ int rtx_render_device(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* ca
     HIPCHK(ctx, hipStreamSynchronize(st));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    *ctx->h_sticky = 0;                           // this call reports its own overflow through the return code
-    return fill_stats(ctx, cam, bands, ctx->h_counters, ms, stats);
+    // This call reports its OWN overflow through the return code (fill_stats reads this call's counters).  A sticky word that
+    // is raised although this call's counters are clean belongs to an EARLIER asynchronous render that was still running when
+    // the check at the top looked: it is reported now, never wiped.
+    const bool raised = *ctx->h_sticky != 0;
+    *ctx->h_sticky = 0;
+    rc = fill_stats(ctx, cam, bands, ctx->h_counters, ms, stats);
+    if (rc == RTX_OK && raised) rc = rtx_earlier_overflow(ctx);
+    return rc;
 }
 
 int rtx_render_device_noalloc(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, int max_depth, rtx_bands bands,

@@ -109,5 +109,9 @@ constexpr uint32_t RTX_F_INTERNAL_NO_LPT = 1u << 17;
 constexpr uint32_t RTX_F_INTERNAL_NO_AHEAD = 1u << 18;
 // RTX_E_CAPACITY (and the message) if an earlier asynchronous render reported an overflow that nobody collected yet
 int rtx_check_sticky(rtx_ctx* ctx);
+// The four list-set events of a lane (ev_probe / ev_main).  They are created WITH the lane (rtx_init, ensure_lanes, the render
+// lanes of a communicator), never lazily by a render: every frame launch that reads a list set records ev_main[set], and every
+// refill of a set waits for it, whichever kind of frame (in-stream probe, split, probe ahead) used the set last.
+int rtx_lane_events(rtx_ctx* ctx, rtx_ctx::Lane* lane);
 
 #endif

@@ -95,6 +95,9 @@ struct rtx_comm {
     unsigned seq = 0;
     // what the last rtx_comm_render_bands queued, for the gather step
     int cur = 0; int W = 0, H = 0; bool want_hit = false;
+    // the buffers of set `cur` exist and cur / W / H / want_hit describe the frame being queued: from here on a rank-local
+    // failure must not keep this rank out of the all-gather (the other ranks enqueue theirs and would wait for ever)
+    bool can_gather = false;
 };
 
 namespace {
@@ -168,6 +171,7 @@ int comm_finish_init(rtx_comm* c) {
         HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
         HIPCHK(ctx, hipMalloc((void**)&ln.d_tile_counts, 64 * sizeof(int32_t)));
+        { const int erc = rtx_lane_events(ctx, &ln); if (erc != RTX_OK) return erc; }
         HIPCHK(ctx, hipMalloc((void**)&c->d_counters[b], RTX_COUNTER_WORDS * sizeof(unsigned long long)));
     }
     return RTX_OK;
@@ -216,9 +220,13 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
     if (!scene || !cam) return RTX_E_INVALID;
     if (cam->hsize <= 0 || cam->vsize <= 0) return rtx_fail(ctx, RTX_E_INVALID, "empty camera");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    c->can_gather = false;
     int rc = comm_reserve(c, cam->hsize, cam->vsize, want_hit);
-    if (rc != RTX_OK) return rc;
+    if (rc != RTX_OK) return rc;                 // (no buffers: this rank cannot take part; an allocation failure is fatal for the job)
     const int b = (int)(c->seq % (unsigned)c->n_sets);
+    c->cur = b; c->W = cam->hsize; c->H = cam->vsize; c->want_hit = want_hit;
+    c->can_gather = true;
+    int deferred = RTX_OK;                       // a rank-local error that is reported AFTER the collective has been queued
     if (c->used[b] && (stats || ctx->opt.pipeline < 2)) HIPCHK(ctx, hipStreamWaitEvent(st, c->ev_gather[b], 0));   // the set's previous gather has read it
     // asynchronous calls render on the set's own lane, behind whatever the caller's stream holds now; a call that wants
     // its counts back is waited for anyway and stays on the caller's stream with the context's counters
@@ -236,8 +244,9 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
             HIPCHK(ctx, hipStreamWaitEvent(rs, c->ev_call[b], 0));
         }
         if (c->used[b]) HIPCHK(ctx, hipStreamWaitEvent(rs, c->ev_gather[b], 0));
-        rc = rtx_check_sticky(ctx);
-        if (rc != RTX_OK) return rc;
+        // an earlier frame of THIS rank overflowed: the frame is still rendered and gathered (the other ranks cannot know and
+        // are queueing their all-gather right now), the error is returned once everything is queued
+        deferred = rtx_check_sticky(ctx);
     }
     // a caller that streams frames (the previous frame is still rendering when this one is queued) is after throughput: the
     // tail of a frame is filled by the start of the next, so the measures that shorten ONE frame's critical path at the
@@ -268,7 +277,7 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
         for (int r = 0; r < n_shares; r++) {
             rc = render(rtx_bands{r, c->world}, c->d_all[b] + (size_t)r * band_px * 3,
                         want_hit ? c->d_all_hit[b] + (size_t)r * band_px : nullptr, stats ? &one : nullptr);
-            if (rc != RTX_OK) return rc;
+            if (rc != RTX_OK) break;
             if (stats) {
                 sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
                 for (int k = 0; k < RTX_EV_COUNT; k++) sum.ev[k] += one.ev[k];
@@ -279,12 +288,13 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
         if (stats) *stats = sum;
     } else {
         rc = render(rtx_bands{c->rank, c->world}, c->d_band[b], want_hit ? c->d_band_hit[b] : nullptr, stats);
-        if (rc != RTX_OK) return rc;
     }
     st = rs;
-    HIPCHK(ctx, hipEventRecord(c->ev_render[b], st));
-    c->cur = b; c->W = cam->hsize; c->H = cam->vsize; c->want_hit = want_hit;
-    return RTX_OK;
+    // (also after a failed render: the gather must be ordered behind whatever part of it was queued)
+    const hipError_t he = hipEventRecord(c->ev_render[b], st);
+    if (rc != RTX_OK) return rc;
+    if (he != hipSuccess) return rtx_fail(ctx, RTX_E_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(he));
+    return deferred;
 }
 
 // step 2 (inside a group when one thread drives several ranks): the all-gather of the current set, on gstream
@@ -434,9 +444,17 @@ int rtx_render_gathered(rtx_comm* c, const rtx_scene* scene, const rtx_camera* c
                         void* d_frame, void* d_hit_frame, void* stream, rtx_stats* stats) {
     if (!c || !d_frame) return RTX_E_INVALID;
     hipStream_t st = stream ? (hipStream_t)stream : c->ctx->stream;
-    int rc = comm_render_bands(c, scene, cam, max_depth, flags, d_hit_frame != nullptr, st, stats);
-    if (rc == RTX_OK) rc = comm_all_gather(c);
+    // The all-gather is a COLLECTIVE: once this rank's buffers exist it is queued whatever happened to the rank's own render
+    // (an earlier frame's overflow, a failed launch: its band buffer then holds the previous or a zero-filled frame), and the
+    // rank-local error is returned afterwards.  A rank that skipped it would leave the others waiting for ever on their gather
+    // streams.  Only a failure before the buffers exist (invalid arguments - the same on every rank - or out of memory) returns
+    // without it.
+    const int rc_local = comm_render_bands(c, scene, cam, max_depth, flags, d_hit_frame != nullptr, st, stats);
+    if (rc_local != RTX_OK && !c->can_gather) return rc_local;
+    const std::string local_err = rc_local != RTX_OK ? c->ctx->err : std::string();
+    int rc = comm_all_gather(c);
     if (rc == RTX_OK) rc = comm_deinterleave(c, d_frame, d_hit_frame);
+    if (rc_local != RTX_OK) { c->ctx->err = local_err; return rc_local; }
     return rc;
 }
 
@@ -471,16 +489,33 @@ int rtx_render_multi(rtx_comm* const* comms, const rtx_scene* const* scenes, int
         HIPCHK(ctx0, hipMalloc((void**)&ctx0->d_hit, npx * 4));
         ctx0->hit_cap = npx * 4;
     }
-    // every GPU renders its bands (queued, nothing waits) ...
-    std::vector<rtx_stats> per(n);
+    // One thread drives all ranks, so the ranks agree on errors by construction — provided every check that can fail on ONE
+    // rank only is made before anything collective is queued: the sticky words and the buffers of all ranks first ...
     int rc = RTX_OK;
-    for (int i = 0; i < n && rc == RTX_OK; i++)
+    for (int i = 0; i < n && rc == RTX_OK; i++) {
+        rc = rtx_check_sticky(comms[i]->ctx);
+        if (rc == RTX_OK && hipSetDevice(comms[i]->ctx->device) != hipSuccess) rc = rtx_fail(comms[i]->ctx, RTX_E_DEVICE, "hipSetDevice failed");
+        if (rc == RTX_OK) rc = comm_reserve(comms[i], cam->hsize, cam->vsize, hit != nullptr);
+        if (rc != RTX_OK && i > 0) ctx0->err = comms[i]->ctx->err;
+    }
+    if (rc != RTX_OK) return rc;
+    // ... then every GPU renders its bands (queued, nothing waits; a failure here ends the call before any rank gathers) ...
+    std::vector<rtx_stats> per(n);
+    for (int i = 0; i < n && rc == RTX_OK; i++) {
         rc = comm_render_bands(comms[i], scenes[i], cam, max_depth, flags, hit != nullptr, comms[i]->ctx->stream, stats ? &per[i] : nullptr);
-    if (rc != RTX_OK) { if (comms[0]->ctx->err.empty()) for (int i = 1; i < n; i++) if (!comms[i]->ctx->err.empty()) ctx0->err = comms[i]->ctx->err; return rc; }
-    // ... one all-gather over all ranks (one thread drives them: a group) ...
+        if (rc != RTX_OK && i > 0) ctx0->err = comms[i]->ctx->err;
+    }
+    if (rc != RTX_OK) return rc;
+    // ... one all-gather over all ranks (one thread drives them: a group).  The HIP calls of the step (device switch, the wait
+    // for the render) are made for ALL ranks before the group opens, so that only ncclAllGather itself runs inside it.
+    for (int i = 0; i < n; i++) {
+        rtx_comm* c = comms[i];
+        if (hipSetDevice(c->ctx->device) != hipSuccess || hipStreamWaitEvent(c->gstream, c->ev_render[c->cur], 0) != hipSuccess)
+            return rtx_fail(ctx0, RTX_E_DEVICE, "rtx_render_multi: cannot order the gather behind the render");
+    }
     NCCLCHK(ctx0, rccl()->GroupStart());
     for (int i = 0; i < n && rc == RTX_OK; i++) rc = comm_all_gather(comms[i]);
-    NCCLCHK(ctx0, rccl()->GroupEnd());
+    { const ncclResult_t ge = rccl()->GroupEnd(); if (ge != ncclSuccess && rc == RTX_OK) rc = nccl_fail(ctx0, "ncclGroupEnd", ge); }
     // ... rank 0 assembles the frame and hands it to the host
     for (int i = 0; i < n && rc == RTX_OK; i++) rc = comm_deinterleave(comms[i], i == 0 ? ctx0->d_rgb : nullptr, i == 0 && hit ? ctx0->d_hit : nullptr);
     for (int i = 0; i < n; i++) {

@@ -630,6 +630,100 @@ def test_probe_ahead_of_queued_frames_does_not_change_them(ctx):
         hip.lib.hipStreamDestroy(st)
 
 
+def test_in_stream_probe_then_probe_ahead_on_a_fresh_context():
+    """on a FRESH context in the default mode (probe_ahead = -1) the first frame of a burst is queued on an
+    idle stream and takes the in-stream probe into list set 0; the next frames find the stream busy and put their probes on the
+    side stream, alternating the sets - the second one refills set 0.  Every frame launch that reads a set now records its
+    event (the events are created with the lane, not by the first ahead-frame), so the refill waits for frame 1.  Frames of
+    alternating sizes (a set that belonged to another frame leaves tiles unrendered or renders them twice) queued back to back
+    on one stream, then on two streams in turn, must equal the frames rendered one at a time.  Large enough that the stream is
+    still busy when the next frame is queued."""
+    import ctypes as C
+    import rtx
+    hip = _Hip()
+    bufs = []
+    streams = []
+    # the expected images come from a context of their own: the context under test must not have rendered anything before
+    ref = rtx.Context(0)
+    cams, wants = [], []
+    try:
+        pw, _ = rtx.load_yaml(parity.scene_text("S4", 960, 544))
+        rsc = ref.scene(pw)
+        for w, h in ((960, 544), (720, 808), (1280, 296)):
+            _, c = rtx.load_yaml(parity.scene_text("S4", w, h))
+            cams.append(c[0]); wants.append(rsc.render(c[0], 5))
+        rsc.close()
+    finally:
+        ref.close()
+    for n_streams in (1, 2):
+        fresh = rtx.Context(0)
+        try:
+            fresh.options(lpt=1, split=0)                   # tile lists on, no split launch; probe_ahead stays at its default
+            sc = fresh.scene(pw)
+            for _ in range(n_streams):
+                st = C.c_void_p()
+                assert hip.lib.hipStreamCreate(C.byref(st)) == 0
+                streams.append(st)
+            sts = streams[-n_streams:]
+            outs = []
+            for k in range(7):
+                cam = cams[k % 3]
+                b = hip.malloc(cam.vsize * cam.hsize * 3, 0x55); bufs.append(b)
+                assert sc.render_device(cam, b.value, 0, 5, stream=sts[k % n_streams].value) is None
+                outs.append((k % 3, b))
+            for st in sts:
+                assert hip.lib.hipStreamSynchronize(st) == 0
+            fresh.poll(wait=True)
+            for k, (i, b) in enumerate(outs):
+                cam = cams[i]
+                got = hip.to_host(b, cam.vsize * cam.hsize * 3, np.uint8).reshape(cam.vsize, cam.hsize, 3)
+                assert np.array_equal(got, wants[i]["rgb"]), (n_streams, k, int((got != wants[i]["rgb"]).any(axis=2).sum()))
+            sc.close()
+        finally:
+            fresh.close()
+    for b in bufs:
+        hip.lib.hipFree(b)
+    for st in streams:
+        hip.lib.hipStreamDestroy(st)
+
+
+def test_stats_render_does_not_wipe_an_earlier_async_overflow(ctx):
+    """a synchronous render (stats) that follows an overflowing ASYNCHRONOUS one on the same stream used to
+    clear the sticky word after its own sync - the earlier frame's overflow was raised during that very sync and lost.  Now a
+    raised word with clean own counters is reported as the earlier render's RTX_E_CAPACITY.  Same for the band-set path of
+    rtx_render."""
+    import rtx
+    hip = _Hip()
+    pw, pc = rtx.load_yaml(parity.scene_text("S4", 960, 544))
+    sc = ctx.scene(pw)
+    buf = hip.malloc(544 * 960 * 3, 0)
+    try:
+        for path in ("device", "host_sets"):
+            ctx.options(lpt=1, split=1, split_class=1, debug=2)     # debug=2: split guard of one iteration
+            assert sc.render_device(pc[0], buf.value, 0, 5) is None  # queued; trips the guard while the next call is made
+            ctx.options(lpt=-1, split=0, split_class=7, debug=0)
+            if path == "host_sets":
+                ctx.set_option("host_sets", 2)
+            with pytest.raises(rtx.RtxError) as e:
+                if path == "device":
+                    sc.render_device(pc[0], buf.value, 0, 5, stats=True)
+                else:
+                    sc.render(pc[0], 5)
+            assert e.value.code == rtx.E_CAPACITY and "earlier" in str(e.value), (path, str(e.value))
+            ctx.set_option("host_sets", 0)
+            # whichever check caught it (the one before queueing or the one after the sync), poll clears it and work goes on
+            rtx.LIB.rtx_ctx_poll(ctx.h, 1)
+            ctx.poll(wait=True)
+            assert sc.render_device(pc[0], buf.value, 0, 5, stats=True).rays > 0
+    finally:
+        ctx.options(lpt=-1, split=-1, split_class=7, debug=0)
+        ctx.set_option("host_sets", 0)
+        rtx.LIB.rtx_ctx_poll(ctx.h, 1)
+        sc.close()
+        hip.lib.hipFree(buf)
+
+
+
 def test_host_render_in_band_sets_equals_one_launch(ctx):
     """rtx_render of a whole frame into host buffers renders large frames as 2..8 interleaved band sets on two lanes and copies
     each set out while the next ones render (option host_sets; 0 = by frame size).  Forced here on small ragged frames:
