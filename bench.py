@@ -2,10 +2,14 @@
 """bench.py — Mrays/s (primary + shadow + secondary) of the MI355X trace-and-shade path.
 
 A "step" is one frame: every rank renders its row-interleaved 8-row tile bands of the SAME frame
-(rank r gets bands r, r+N, ...) with the scene resident in HBM; for N > 1 the bands are all-gathered
-and de-interleaved INSIDE the product (rtx_render_gathered in include/rtx.h: one ncclAllGather over
-RCCL/xGMI on the library's own stream, overlapped with the next frame's render).  Total work per step
-is fixed as N grows -> "strong" scaling; value = whole-job rays per second.
+(rank r gets bands r, r+N, ...) with the scene resident in HBM, and the bands are all-gathered and
+de-interleaved INSIDE the product (rtx_render_gathered in include/rtx.h: one ncclAllGather over
+RCCL/xGMI on the library's own stream, overlapped with the next frame's render).  EVERY N takes that
+entry point, N = 1 included (a one-rank RCCL communicator: the same calls, the gather degenerates to a
+copy), so the 1 -> 8 curve compares like with like: `value` / `ms_per_step` are the streamed rate (the
+K frames are queued back to back, up to three in flight on the library's render lanes) at every N, and
+`ms_per_frame_one_at_a_time` is the latency of one frame (queue, wait, repeat) at every N.  Total work
+per step is fixed as N grows -> "strong" scaling; value = whole-job rays per second.
 
 Launch: `python bench.py --gpus N ...`.  For N > 1 without a torch.distributed environment the script
 starts its N ranks itself (a child `python -m torch.distributed.run`, before anything touches the
@@ -17,7 +21,10 @@ stream; `valu_issue_frac`, `resident_waves` and `traffic` come from the rocprofv
 profiles/<tag>_counters.json together with the git revision they were taken at), `cpu_baseline` (the
 CPU oracle — a C++ restatement of the single-threaded reference, `kind: "port"` — timed on a bounded
 tile sample of the same frame on this box's host cores, rank 0, N = 1 only) and `secondary` (the other
-3840x2160 configuration, S3, measured the same way in the same run).
+3840x2160 configuration, S3, measured the same way in the same run).  At N = 1 the line also carries
+`kernel_region` (the same K frames through rtx_render_device, one HIP event pair per launch on the
+launch stream: the average launch duration the roofline is priced with) and `host_render_ms`
+(rtx_render of the same frame into pageable host memory: what Camera::render, camera.rs:39-54, returns).
 """
 import argparse
 import json
@@ -169,7 +176,19 @@ def main():
     # together), the run falls back to torch.distributed's all-gather of the same compact bands and says so in the line,
     # so that a scaling run still yields a labelled number; RTX_BENCH_NO_PRODUCT_COMM=1 rehearses that path.
     comm, comm_error = None, None
+    comm_kind = "rccl"
     torch_gather = False
+    if N == 1 and not force_comm:
+        # N = 1: the same entry point over a one-rank RCCL communicator (no torch.distributed needed: the id stays here).  If
+        # RCCL does not come up, the library's loopback communicator (same render lanes, same de-interleave, no ncclAllGather)
+        # takes its place and the line says so.
+        try:
+            comm = rtx.Comm(ctx, rtx.comm_unique_id(), 0, 1)
+        except rtx.RtxError as e:
+            comm_error = str(e); comm_kind = "loopback"
+            comm = rtx.Comm.loopback(ctx, 1)
+            print("bench.py: one-rank RCCL communicator did not come up (%s); using the loopback communicator" % comm_error,
+                  file=sys.stderr, flush=True)
     if (N > 1 or force_comm) and backend == "nccl":
         ok = torch.ones(1, dtype=torch.int32, device=dev)
         idt = torch.zeros(rtx.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
@@ -206,7 +225,7 @@ def main():
         bands = (rank, N)
         rows_pad = rtx.LIB.rtx_band_rows_padded(height, N)
         local = torch.zeros(rows_pad * width * 3, dtype=torch.uint8, device=dev)
-        frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=dev) for _ in range(4)] if (N > 1 or comm is not None) else None
+        frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=dev) for _ in range(4)] if comm is not None else None
         gathered_host = torch.zeros((N, rows_pad * width * 3), dtype=torch.uint8) if (N > 1 and comm is None and not torch_gather) else None
         if torch_gather:     # fallback gather: frame row y is row (y // 8 // N) * 8 + y % 8 of rank (y // 8) % N's compact buffer
             y = torch.arange(height, device=dev)
@@ -255,14 +274,9 @@ def main():
         if N > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         for k in range(steps):
-            if comm is None and N == 1:
-                ev[k][0].record()
             step(k)
-            if comm is None and N == 1:
-                ev[k][1].record()
         if comm is not None:
             comm.wait()                               # host waits for the last gather + de-interleave (and polls the sticky error)
         torch.cuda.synchronize()
@@ -277,8 +291,26 @@ def main():
             got = frame_dev.view(-1) if torch_gather else frames[(steps - 1) & 3]
             assert torch.equal(got, whole), "gathered frame differs from the single-GPU frame"
             print("bench.py: gathered frame == single-GPU frame (rank %d)" % rank, file=sys.stderr, flush=True)
-        if comm is None and N == 1:
+        kernel_region = None
+        if N == 1:
+            # the roofline's kernel time: the same K frames through rtx_render_device, queued back to back on `stream`, one HIP
+            # event pair per launch on that stream (inside the region above, consecutive frames run on alternating render lanes
+            # and overlap, so a launch's own duration cannot be read off it)
+            for k in range(warmup):
+                scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            k0 = time.perf_counter()
+            for k in range(steps):
+                ev[k][0].record()
+                scene.render_device(cam, local.data_ptr(), 0, 5, bands, rtx.F_BANDS_COMPACT, stream, False)
+                ev[k][1].record()
+            torch.cuda.synchronize()
+            k1 = time.perf_counter()
+            ctx.poll(wait=True)
             kern = sum(a.elapsed_time(b) for a, b in ev) / steps
+            kernel_region = {"entry_point": "rtx_render_device", "steps": steps, "ms_per_step": (k1 - k0) / steps * 1000.0,
+                             "kernel_ms_avg": kern, "mrays_per_s": rays_frame * steps / (k1 - k0) / 1e6}
         else:
             # per-rank kernel time of its share, from the library's own HIP events (3 synchronous renders after the timed region:
             # inside it consecutive frames run on alternating render lanes and overlap each other and the gathers)
@@ -296,6 +328,18 @@ def main():
                 comm.wait()
                 lat.append(time.perf_counter() - a)
             one = min(lat) * 1000.0
+        host_ms = None
+        if N == 1:
+            # what Camera::render (camera.rs:39-54) returns: the frame in HOST memory (pageable, as a caller's Vec would be).
+            # The first whole-frame rtx_render of a context takes the one-launch path, the later ones the band sets.
+            import numpy as np
+            img = np.zeros((height, width, 3), np.uint8)
+            lat = []
+            for k in range(4):
+                a = time.perf_counter()
+                scene.render(cam, 5, want_hit=False, out=(img, None))
+                lat.append((time.perf_counter() - a) * 1000.0)
+            host_ms = {"first_call": lat[0], "steady": min(lat[1:]), "note": "rtx_render into pageable host memory, wall clock of the call"}
         t = torch.tensor([t1 - t0, kern, one], dtype=torch.float64, device=dev)
         if N > 1:
             all_reduce(t, dist.ReduceOp.MAX)
@@ -315,6 +359,9 @@ def main():
                 "valu_issue_frac": pmc["valu_issue_frac"] if pmc else None,
                 "valu_busy_frac": pmc["valu_busy_frac"] if pmc else None,
                 "resident_waves": pmc["resident_waves"] if pmc else None,
+                "lane_util_pmc": pmc["lane_util"] if pmc else None,
+                "hbm_gbps": pmc["hbm_gbps"] if pmc else None,
+                "spilled_vgprs": pmc["spilled_vgprs"] if pmc else None, "spilled_sgprs": pmc["spilled_sgprs"] if pmc else None,
                 "pmc_source": ({"file": "profiles/" + pmc["file"], "git_rev": pmc["git_rev"], "kernel_ms_in_pass": pmc["kernel_ms"]} if pmc else None),
                 "kernel": "trace_shade_kernel", "kernel_ms": kern_ms,
                 "algorithmic_flops_per_frame": float(counts[3]), "executed_f64_flops_per_frame": float(counts[4]),
@@ -327,13 +374,15 @@ def main():
                 "value": rays_frame * steps / elapsed / 1e6, "ms_per_step": elapsed / steps * 1000.0,
                 "traced_mrays_per_s": rays_traced * steps / elapsed / 1e6, "rays_traced": rays_traced,
                 "rays": {"primary": int(counts[0]), "shadow": int(counts[1]), "secondary": int(counts[2])}, "roofline": roof,
-                "one_ms": one_ms}
+                "one_ms": one_ms, "kernel_region": kernel_region, "host_ms": host_ms}
 
     m = measure(args.workload, args.width, args.height, args.steps, args.warmup)
     out = None
     if rank == 0:
-        gather = ("row-interleaved 8-row bands x%d + one ncclAllGather per frame inside the product (rtx_render_gathered), "
-                  "up to three frames in flight on alternating render lanes" % N) if comm is not None else \
+        gather = ("row-interleaved 8-row bands x%d + one ncclAllGather per frame inside the product (rtx_render_gathered, the SAME entry "
+                  "point at every N; %s), K frames queued back to back with up to three in flight on alternating render lanes: value / "
+                  "ms_per_step = that streamed rate at every N, ms_per_frame_one_at_a_time = one frame queued, waited for, repeated"
+                  % (N, "RCCL communicator" if comm_kind == "rccl" else "LOOPBACK communicator, RCCL did not come up: %s" % comm_error)) if comm is not None else \
                  ("row-interleaved 8-row bands x%d, FALLBACK gather through torch.distributed (the product's communicator did not "
                   "come up: %s)" % (N, comm_error) if torch_gather else
                   "row-interleaved 8-row bands x%d, gloo REHEARSAL gather through host memory" % N if N > 1 else "1 GPU")
@@ -355,6 +404,10 @@ def main():
                "roofline": m["roofline"]}
         if comm is not None:
             out["ms_per_frame_one_at_a_time"] = m["one_ms"]      # ms_per_step is the streamed rate (up to 3 frames in flight)
+        if m["kernel_region"] is not None:
+            out["kernel_region"] = m["kernel_region"]
+        if m["host_ms"] is not None:
+            out["host_render_ms"] = m["host_ms"]
     if N == 1 and not args.no_secondary and args.workload == "S4" and not args.width and not args.height:
         s3 = measure("S3", 0, 0, args.steps, args.warmup)
         if rank == 0:

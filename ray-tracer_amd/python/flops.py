@@ -84,7 +84,20 @@ def pmc_counters(workload, path=None):
         return None
     c = w["frame"]                                   # per frame: frame launch (+ probe / split launches when used)
     cyc = c["GRBM_GUI_ACTIVE"] / N_XCD
-    return {"file": os.path.basename(path), "git_rev": rec.get("git_rev"), "kernel_ms": w.get("kernel_ms"),
+    # lane utilisation INSIDE issued vector instructions (exec-mask): both counters from the one "sq3" pass (older records:
+    # the two counters sat in different passes, whose kernel times differ by a few per cent)
+    if "sq3:SQ_THREAD_CYCLES_VALU" in c:
+        lane_util = c["sq3:SQ_THREAD_CYCLES_VALU"] / (64.0 * c["sq3:SQ_ACTIVE_INST_VALU"])
+    elif "SQ_THREAD_CYCLES_VALU" in c:
+        lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+    else:
+        lane_util = None
+    by_pass = w.get("kernel_ms_by_pass", {})
+    ms_f, ms_w = by_pass.get("fetchsz", w.get("kernel_ms")), by_pass.get("write", w.get("kernel_ms"))
+    hbm_gbps = (c["FETCH_SIZE"] * 1024 / (ms_f * 1e-3) + c["WRITE_SIZE"] * 1024 / (ms_w * 1e-3)) / 1e9 if ms_f and ms_w else None
+    kres = rec.get("kres", {}).get("CSG=%d COUNT=0 PROBE=0 SPLIT=0" % (1 if workload == "S5" else 0), {})
+    return {"lane_util": lane_util, "hbm_gbps": hbm_gbps,
+            "spilled_vgprs": kres.get("VGPRs Spill"), "spilled_sgprs": kres.get("SGPRs Spill"),"file": os.path.basename(path), "git_rev": rec.get("git_rev"), "kernel_ms": w.get("kernel_ms"),
             "traffic_bytes": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
             "fetch_bytes": int(c["FETCH_SIZE"] * 1024), "write_bytes": int(c["WRITE_SIZE"] * 1024),
             "valu_issue_frac": c["SQ_INSTS_VALU"] / (cyc * N_SIMD / 4.0),

@@ -821,6 +821,44 @@ def test_band_shares_of_2_3_8_ranks_assemble_to_the_full_frame_on_the_device(ctx
             hip.lib.hipFree(b)
 
 
+def test_band_path_at_full_size_s5_8k_over_8_ranks(ctx):
+    """C5 (BASELINE.json: 7680x4320 on 8 GPUs) through the product's N = 8 data path AT SIZE on the one GPU there is: a loopback
+    communicator of 8 ranks renders every rank's compact band set (540 bands -> 68 per rank, 67.5 rounded up: the last rank's
+    set ends in a padding band; 12.5 MB per rank, 99.5 MB gathered) where the all-gather would deliver it and the product's
+    de-interleave kernel (long long indexing) assembles frame and hit ids.  Must equal rtx_render byte for byte."""
+    import rtx
+    hip = _Hip()
+    w, h = 7680, 4320
+    pw, pc = rtx.load_yaml(parity.scene_text("S5", w, h))
+    sc = ctx.scene(pw)
+    bufs = []
+    comm = rtx.Comm.loopback(ctx, 8)
+    try:
+        assert rtx.LIB.rtx_band_rows_padded(h, 8) == 544
+        ctx.set_option("host_sets", 1)
+        want = sc.render(pc[0], 5)
+        frame = hip.malloc(h * w * 3, 0x33); ids = hip.malloc(h * w * 4, 0x44)
+        bufs += [frame, ids]
+        for rep in range(2):                                          # asynchronous (render lanes), then with stats
+            stats = comm.render_gathered(sc, pc[0], frame.value, ids.value, 5, stats=(rep == 1))
+            comm.wait()
+            got = hip.to_host(frame, h * w * 3, np.uint8).reshape(h, w, 3)
+            assert np.array_equal(got, want["rgb"]), (rep, int((got != want["rgb"]).any(axis=2).sum()))
+            assert np.array_equal(hip.to_host(ids, h * w * 4, np.int32).reshape(h, w), want["hit"]), rep
+            if stats is not None:
+                assert (stats.rays_primary, stats.rays_shadow, stats.rays_secondary) == \
+                       (want["stats"].rays_primary, want["stats"].rays_shadow, want["stats"].rays_secondary)
+            assert hip.lib.hipMemset(frame, 0x33, h * w * 3) == 0 and hip.lib.hipMemset(ids, 0x44, h * w * 4) == 0
+        ctx.poll(wait=True)
+    finally:
+        ctx.set_option("host_sets", 0)
+        comm.close()
+        sc.close()
+        for b in bufs:
+            hip.lib.hipFree(b)
+
+
+
 def test_multi_gpu_entry_points_with_a_one_rank_communicator(ctx, tmp_path):
     """The C-ABI multi-GPU render (rtx_comm_* / rtx_render_gathered / rtx_render_multi, `rtx --gpus N`): bands of rank r of N,
     ONE ncclAllGather (RCCL, opened by the library itself), de-interleave kernel.  The box has one GPU, so the communicator

@@ -9,7 +9,10 @@ import json
 import sqlite3
 import sys
 
-SETS = ["sq", "sq2", "tcc", "fetchsz", "write"]
+SETS = ["sq", "sq2", "sq3", "tcc", "fetchsz", "write"]
+# counters of the "sq3" pass (lane utilisation: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), both from ONE pass) are stored
+# under "sq3:<name>": some of them ride in the "sq" pass as well and the counters of a ratio must come from one pass
+PREFIXED = {"sq3"}
 
 
 def kernels_of(db):
@@ -35,7 +38,7 @@ def main():
     tag, rev, wls = sys.argv[1], sys.argv[2], sys.argv[3:]
     out = {"tag": tag, "git_rev": rev, "workloads": {}}
     for wl in wls:
-        frame, main_, kms, names = {}, {}, None, {}
+        frame, main_, kms, names, kms_by_set = {}, {}, None, {}, {}
         for s in SETS:
             dbs = glob.glob("gpurun_out/pmc_%s_%s_%s/**/*.db" % (tag, wl, s), recursive=True)
             if not dbs:
@@ -47,17 +50,31 @@ def main():
             mains = [n for n in ts if not targs(n)[2] and not targs(n)[3]]
             main_name = max(mains, key=lambda n: ts[n][0])
             n_frames = ts[main_name][0]
+            kms_by_set[s] = sum(c * a for n, (c, a) in ts.items()) / n_frames / 1e6
             if s == "sq":
-                kms = sum(c * a for n, (c, a) in ts.items()) / n_frames / 1e6
+                kms = kms_by_set[s]
                 names = {n[:60]: c for n, (c, a) in ts.items()}
             for n in ts:
                 for c, avg in ctr.get(n, {}).items():
+                    if s in PREFIXED:
+                        c = s + ":" + c
                     per_frame = avg * ts[n][0] / n_frames          # launches of this instantiation per frame
                     frame[c] = frame.get(c, 0.0) + per_frame
                     if n == main_name:
                         main_[c] = avg
         if frame:
-            out["workloads"][wl] = {"kernel_ms": kms, "launches": names, "frame": frame, "main": main_}
+            out["workloads"][wl] = {"kernel_ms": kms, "kernel_ms_by_pass": kms_by_set, "launches": names, "frame": frame, "main": main_}
+    # registers / spills of the kernel instantiations at this revision: tools/kres.sh > profiles/<tag>_kres.txt (run where hipcc
+    # cross-compiles, before the profiling call), one line per instantiation
+    import os
+    import re
+    kres = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "%s_kres.txt" % tag)
+    if os.path.exists(kres):
+        out["kres"] = {}
+        for line in open(kres):
+            m = re.match(r"(CSG=\d COUNT=\d PROBE=\d SPLIT=\d) (.*)", line.strip())
+            if m:
+                out["kres"][m.group(1)] = {k.strip().rsplit(" ", 1)[0]: int(k.strip().rsplit(" ", 1)[1]) for k in m.group(2).split("|")}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 

@@ -1,4 +1,5 @@
 # usage (from the repo root, on the GPU box): bash tools/profile_round.sh TAG GIT_REV
+# (before the call, where hipcc cross-compiles: tools/kres.sh > profiles/TAG_kres.txt — the spill table the counters file quotes)
 # bench lines, a kernel trace and the PMC passes of S3 / S4 / S5 -> gpurun_out/<TAG>_*; copy what is to be judged into profiles/
 set -e
 tag=$1; rev=${2:-unknown}
@@ -10,6 +11,6 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -
 python3 tools/rocpd_summary.py $(find gpurun_out/${tag}_prof -name "*.db" | head -1) > gpurun_out/${tag}_S4_kernel_trace_stats.txt
 for wl in S3 S4 S5; do
   bash tools/pmc_passes.sh ${tag}_$wl $wl
-  for s in sq sq2 tcc fetchsz write; do python3 tools/rocpd_summary.py $(find gpurun_out/pmc_${tag}_${wl}_$s -name "*.db" | head -1); done > gpurun_out/${tag}_${wl}_pmc.txt
+  for s in sq sq2 sq3 tcc fetchsz write; do python3 tools/rocpd_summary.py $(find gpurun_out/pmc_${tag}_${wl}_$s -name "*.db" | head -1); done > gpurun_out/${tag}_${wl}_pmc.txt
 done
 python3 tools/pmc_counters.py $tag $rev S3 S4 S5 > gpurun_out/${tag}_counters.json
