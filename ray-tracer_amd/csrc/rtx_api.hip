@@ -563,6 +563,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.host_sets = env_int("RTX_HOST_SETS", 0);
     c->opt.stream_lpt = env_int("RTX_STREAM_LPT", -1);
     c->opt.probe_ahead = env_int("RTX_PROBE_AHEAD", -1);
+    c->opt.hctx = env_int("RTX_HCTX", -1);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -645,6 +646,7 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "host_sets") c->opt.host_sets = value;
     else if (n == "stream_lpt") c->opt.stream_lpt = value;
     else if (n == "probe_ahead") c->opt.probe_ahead = value;
+    else if (n == "hctx") c->opt.hctx = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
 }
@@ -865,6 +867,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
         if (rp.tile_mul == 0) rp.tile_mul = 1;
     }
     rp.sticky = ctx->d_sticky;
+    rp.hctx = ctx->opt.hctx;
     rp.compact = (flags & RTX_F_BANDS_COMPACT) ? 1 : 0;
     rp.no_early_out = (flags & RTX_F_NO_SHADOW_EARLY_OUT) ? 1 : 0;
 

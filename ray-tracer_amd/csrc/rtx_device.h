@@ -184,6 +184,7 @@ struct RenderParams {
     unsigned long long* sticky;   // device-visible host word: set non-zero when this launch reports an overflow (asynchronous renders)
     int32_t tile_mul;         // block b renders tile (b * tile_mul) mod n_tiles: coprime with n_tiles, spreads heavy image
                               //   regions over the whole dispatch instead of leaving them to the tail
+    int32_t hctx;             // hit context in LDS (rtx_kernel.hip, template flag HCTX): -1 = where the LDS budget allows, 0 / 1 = forced
 };
 
 // counters[]: 0 radiance rays, 1 shadow rays, 2 overflow pixels, 3.. events

@@ -22,6 +22,7 @@ struct rtx_opts {
                              // caller's stream is busy, 0 = never, 1 = always
     int stream_lpt = -1;     // streaming callers of rtx_render_gathered keep the tile-order probe: -1 = by dispatch length, 0 / 1 = forced
     int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
+    int hctx = -1;           // hit context in LDS instead of registers: -1 = where the wave's LDS budget allows (rtx_kernel.hip), 0 / 1 = forced
     int pipeline = 3;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
                              // 2..4; below 2 = every frame on the caller's stream)
 };

@@ -288,7 +288,12 @@ const uint32_t LBIT = 0x80000000u;
 #ifndef RTX_SPLIT_BITS
 #define RTX_SPLIT_BITS 2
 #endif
-template <bool CSG, bool COUNT, bool PROBE = false, bool SPLIT = false>
+// HCTX: the hit context (point, eye vector, normal of the hit being shaded: 9 doubles per lane) waits in LDS instead of registers
+// while the hit's shadow rays are traced.  In registers it is what the compiler spills (the CSG kernels keep all of it in
+// scratch, the others part of it: written per hit, re-read per light, 4.6 GB of the 4K glass frame's fabric writes); in LDS it
+// costs 4.6 KB per wave, which scenes with several ray-stack slots cannot afford (S3 +22 %, S5 +21 % from the lost occupancy).
+// The launcher therefore picks it per launch: only where the wave's LDS still fits the kernel's occupancy target with it.
+template <bool CSG, bool COUNT, bool PROBE = false, bool SPLIT = false, bool HCTX = false>
 __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
@@ -370,8 +375,18 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     }
 #ifdef RTX_DIAG_PHASE
 #define EV(e, n) do { if (COUNT && (e) != RTX_EV_POW && (e) != RTX_EV_SCHLICK && (e) != RTX_EV_REFR && (e) != RTX_EV_BACKFACE) ev[e] += (n); } while (0)
+#elif defined(RTX_DIAG_DIV)
+// diagnostic build (tools/divergence.py): the event slots carry lane-occupancy figures of the divergent parts of an iteration
+// instead of the reference-defined events.  DV(i, n): this lane adds n to slot i; DVW(i, pred): 64 x (wave has a lane with pred)
+#define EV(e, n) do { } while (0)
+#define DV(i, n) do { if (COUNT) ev[i] += (n); } while (0)
+#define DVW(i, pred) do { if (COUNT && __any(pred)) { if (lane == (int)__builtin_ctzll(__ballot(1))) ev[i] += 64; } } while (0)
 #else
 #define EV(e, n) do { if (COUNT) ev[e] += (n); } while (0)
+#endif
+#ifndef DV
+#define DV(i, n) do { } while (0)
+#define DVW(i, pred) do { } while (0)
 #endif
 #ifdef RTX_TIMING
     unsigned long long tm_ffwd = 0, tm_body = 0, tm_shade = 0, tm_other = 0, tm_prep = 0, tm_light = 0, tm_mark = __builtin_amdgcn_s_memtime();
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     Frame frames[RTX_MAX_DEPTH + 1];      // + 1: the hit at budget 0 (sp == max_depth) still parks its partial light sum in frames[sp]
     bool primary = !spare;                // (the spare lanes of a split wave never trace a primary ray)
     // the hit being shaded while its shadow rays are traced (PreparedComputations, world.rs:225-256)
-    V3 hp = {0, 0, 0}, eyev = {0, 0, 0}, nv = {0, 0, 0};
+    V3 hp_r = {0, 0, 0}, eyev_r = {0, 0, 0}, nv_r = {0, 0, 0};   // (HCTX: unused — the context waits in LDS)
     int hop = 0;                          // op index of the hit shape
     int hmat = 0;                         // its material
     int n1op = -1, n2op = -1;             // ops whose refractive indices are n1 / n2 (-1: vacuum, 1.0)
@@ -474,6 +489,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     volatile int* const mb_state = (volatile int*)(mb_ + 3 * 64);
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
+    // HCTX: the hit context's LDS area, after everything else: [9][64] doubles
+    double* const hctx = (double*)(((uintptr_t)(SPLIT ? (const volatile void*)(mb_rem + 64) : (const volatile void*)mb_) + 7) & ~(uintptr_t)7) + lane;
 
     bool phaseR = false;                  // the kind of ray the last iteration traced (see the top of the loop)
     bool guard_hit = false;
@@ -508,6 +525,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         if (mode == MODE_RADIANCE) n_radiance++;
         else if (mode == MODE_SHADOW) n_shadow++;
         EV(RTX_EV_LANE_SLOTS, 1);         // every lane, busy or not: 64 per wave trace
+        DV(0, 1); DV(1, mode != MODE_DONE ? 1 : 0);                       // slot 0: lane-slots of all iterations, 1: lanes tracing a ray
 
         // running state instead of a sorted hit list; shapes are identified by op index
         double best_t = 0.0; int best_op = -1; bool best_inside = false;
@@ -1003,13 +1021,37 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         // ---- shapes: every lane walks ITS OWN surviving children; node records come through per-lane
                         // vector loads.  ObjectStore::intersect (object_store.rs:243-260) for one shape per lane.
                         unsigned sc_cand = decided ? 0u : (cand & shape_mask);
+#ifdef RTX_DIAG_DIV
+                        if (COUNT) {
+                            // slot 2: (lane, candidate) pairs of this chunk; 3: 64 x the longest lane's candidates (the rounds the loop
+                            // below runs if nobody stops early); 4: 64 x rounds really run; 5: lanes busy in those rounds
+                            int pc = __builtin_popcount(sc_cand), mx = pc;
+                            for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(mx, o, 64); mx = w > mx ? w : mx; }
+                            ev[2] += pc; ev[3] += mx;             // (every lane adds the maximum: 64 x max per wave)
+                        }
+#endif
+#ifdef RTX_TOUCH_NEXT
+                        int k_cur = 0;
+                        if (sc_cand != 0) { const int i0 = __builtin_ctz(sc_cand); k_cur = (sc.bodies + (op0 >= 0 ? op0 + i0 : sc.list_ops[child_base + i0]))->kind; }
+#endif
                         while (__any(sc_cand != 0)) {
+                            DV(4, 1); DV(5, sc_cand != 0 ? 1 : 0);
                             if (sc_cand != 0) {
                                 const int i = __builtin_ctz(sc_cand);
                                 sc_cand &= sc_cand - 1;
                                 const int idx = op0 >= 0 ? op0 + i : sc.list_ops[child_base + i];
                                 const OpBody* gb = sc.bodies + idx;
+#ifdef RTX_TOUCH_NEXT
+                                // the KIND of this lane's next candidate is requested now and used in the next round: its record's
+                                // line is then on the way to the L1 while this candidate's test runs
+                                const int k1 = k_cur;
+                                if (sc_cand != 0) {
+                                    const int i2 = __builtin_ctz(sc_cand);
+                                    k_cur = (sc.bodies + (op0 >= 0 ? op0 + i2 : sc.list_ops[child_base + i2]))->kind;
+                                }
+#else
                                 const int k1 = gb->kind;
+#endif
                                 V3 lo = xf_point(gb->inv, gb->w33, gb->div != 0, po);
                                 V3 ld = xf_vector(gb->inv, pd);
                                 EV(RTX_EV_X_XFORM, 1);
@@ -1155,6 +1197,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         }
 #endif
         // ================================================================= SHADE
+        // the hit being shaded: this iteration's view of it.  HCTX: read back from LDS by the lanes whose shadow ray has just been
+        // traced (a radiance lane computes a new one below), so nothing of it is live across the traversal; else the registers
+        V3 hp = hp_r, eyev = eyev_r, nv = nv_r;
+        if (HCTX && mode == MODE_SHADOW) {
+            hp = V3{hctx[0], hctx[64], hctx[128]}; eyev = V3{hctx[192], hctx[256], hctx[320]}; nv = V3{hctx[384], hctx[448], hctx[512]};
+        }
         bool returning = false;                 // lane has a finished colour to hand to its parent frame
         double rr = 0.0, rg = 0.0, rb = 0.0;
         bool lights_done = false;
@@ -1163,6 +1211,9 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         bool newray = false;                    // lane launches (nro, nrd) next
         V3 nro = {0, 0, 0}, nrd = {0, 0, 0};
 
+        DVW(6, mode == MODE_RADIANCE); DV(7, mode == MODE_RADIANCE ? 1 : 0);          // 6: 64 x iterations with a radiance lane, 7: those lanes
+        DVW(8, mode == MODE_RADIANCE && best_op >= 0); DV(9, (mode == MODE_RADIANCE && best_op >= 0) ? 1 : 0);   // PreparedComputations: waves x 64 / lanes
+        DVW(10, mode == MODE_SHADOW); DV(11, mode == MODE_SHADOW ? 1 : 0);            // lighting block: waves x 64 / lanes
         if (mode == MODE_RADIANCE) {
             if (primary) {
                 primary = false;
@@ -1210,6 +1261,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 }
                 nv = ln;
                 if (dot3(nv, eyev) < 0.0) nv = neg(nv);                           // world.rs:232-237
+                if (HCTX) {
+                    hctx[0] = hp.x; hctx[64] = hp.y; hctx[128] = hp.z; hctx[192] = eyev.x; hctx[256] = eyev.y; hctx[320] = eyev.z;
+                    hctx[384] = nv.x; hctx[448] = nv.y; hctx[512] = nv.z;
+                } else { hp_r = hp; eyev_r = eyev; nv_r = nv; }
                 // get_refractive_indices_at (world.rs:258-296) from the running state: remember
                 // WHICH shapes supply n1 / n2; the indices themselves are read when the children are decided
                 n1op = c1s;
@@ -1249,6 +1304,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     }
                 }
             }
+            DVW(12, m->kind != RTX_PAT_PLAIN); DV(13, m->kind != RTX_PAT_PLAIN ? 1 : 0);   // pattern look-up with its transforms: waves x 64 / lanes
             const double ir = L->intensity[0], ig = L->intensity[1], ib = L->intensity[2];
             const double er = pcr * ir, eg = pcg * ig, eb = pcb * ib;             // effective_color
             V3 lightv = normalize3(V3{L->pos[0], L->pos[1], L->pos[2]} - hp);
@@ -1257,6 +1313,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             double dr = 0.0, dg = 0.0, db = 0.0, spr = 0.0, spg = 0.0, spb = 0.0;
             const double ldn = dot3(lightv, nv);
             if (ldn < 0.0) EV(RTX_EV_BACKFACE, 1);
+            DVW(14, !(in_shadow || ldn < 0.0)); DV(15, !(in_shadow || ldn < 0.0) ? 1 : 0);   // lit: diffuse + specular: waves x 64 / lanes
             if (!(in_shadow || ldn < 0.0)) {
                 const double dif = m->diffuse;
                 dr = er * dif * ldn; dg = eg * dif * ldn; db = eb * dif * ldn;
@@ -1321,6 +1378,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         }
         TMS(tm_ffwd);
 
+        DVW(16, lights_done); DV(17, lights_done ? 1 : 0);                            // children decision: waves x 64 / lanes
         if (lights_done) {
             // ---- rest of shade_hit (world.rs:138-148): decide the children
             const MaterialRec* m = sc.materials + hmat;
@@ -1628,25 +1686,23 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
     size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 15) & ~(size_t)15) +
                  (size_t)sc->csg_prog_max * sizeof(uint32_t);
     if (split) lds += 64 * (3 * sizeof(double) + 2 * sizeof(int));
+    // hit context in LDS (template flag HCTX): only if the wave's LDS still fits the occupancy the kernel is built for
+    // (4 waves per SIMD = 16 per CU of 160 KB without CSG, 3 = 12 with; 256 bytes of slack per wave for the allocation granule)
+    const size_t hctx_bytes = 8 + 9 * 64 * sizeof(double);
+    const size_t waves_cu = 4 * (size_t)(sc->has_csg ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES);
+    const bool hctx = rp->hctx >= 0 ? rp->hctx != 0 : (lds + hctx_bytes + 256) * waves_cu <= (size_t)160 * 1024;
+    if (hctx) lds += hctx_bytes;
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
-    if (rp->probe) {
-        if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-        else     hipLaunchKernelGGL((trace_shade_kernel<false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-    } else if (split) {
-        if (count_events) {
-            if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-            else     hipLaunchKernelGGL((trace_shade_kernel<false, true, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-        } else {
-            if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-            else     hipLaunchKernelGGL((trace_shade_kernel<false, false, false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-        }
-    } else if (count_events) {
-        if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-        else     hipLaunchKernelGGL((trace_shade_kernel<false, true>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-    } else {
-        if (csg) hipLaunchKernelGGL((trace_shade_kernel<true, false>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-        else     hipLaunchKernelGGL((trace_shade_kernel<false, false>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters);
-    }
+    const bool count = count_events != 0;
+#define RTX_LAUNCH(C, N, P, S, H) hipLaunchKernelGGL((trace_shade_kernel<C, N, P, S, H>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters)
+#define RTX_PICK_H(C, N, P, S) do { if (hctx) RTX_LAUNCH(C, N, P, S, true); else RTX_LAUNCH(C, N, P, S, false); } while (0)
+#define RTX_PICK_C(N, P, S) do { if (csg) RTX_PICK_H(true, N, P, S); else RTX_PICK_H(false, N, P, S); } while (0)
+    if (rp->probe) RTX_PICK_C(false, true, false);
+    else if (split) { if (count) RTX_PICK_C(true, false, true); else RTX_PICK_C(false, false, true); }
+    else { if (count) RTX_PICK_C(true, false, false); else RTX_PICK_C(false, false, false); }
+#undef RTX_PICK_C
+#undef RTX_PICK_H
+#undef RTX_LAUNCH
     return hipGetLastError();
 }

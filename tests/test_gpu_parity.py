@@ -724,6 +724,35 @@ def test_stats_render_does_not_wipe_an_earlier_async_overflow(ctx):
 
 
 
+@pytest.mark.parametrize("name,w,h", [("S4", 333, 171), ("S5", 320, 200), ("S3", 200, 120), ("S1", 200, 100)])
+def test_hit_context_in_lds_does_not_change_the_image(ctx, name, w, h):
+    """The hit context (point, eye vector, normal) waits either in registers or in LDS while a hit's shadow rays are traced
+    (template flag HCTX of the kernel, picked per launch from the wave's LDS budget; option "hctx" forces it).  Placement only:
+    image, hit ids, ray and event counts must be identical, also with tile lists and split tiles on."""
+    import rtx
+    pw, pc = rtx.load_yaml(parity.scene_text(name, w, h))
+    sc = ctx.scene(pw)
+    try:
+        got = {}
+        for hctx in (0, 1):
+            ctx.set_option("hctx", hctx)
+            got[hctx] = [sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)]
+            ctx.options(lpt=1, split=1, split_class=1)
+            got[hctx].append(sc.render(pc[0], 5))
+            ctx.options(lpt=-1, split=-1, split_class=7)
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["hit"], b["hit"]), name
+            assert a["stats"].rays == b["stats"].rays
+        ea, eb = got[0][0]["stats"].events(), got[1][0]["stats"].events()
+        assert ea == eb, name
+        assert np.array_equal(got[0][0]["rgb"], got[0][1]["rgb"])
+    finally:
+        ctx.options(lpt=-1, split=-1, split_class=7)
+        ctx.set_option("hctx", -1)
+        sc.close()
+
+
+
 def test_host_render_in_band_sets_equals_one_launch(ctx):
     """rtx_render of a whole frame into host buffers renders large frames as 2..8 interleaved band sets on two lanes and copies
     each set out while the next ones render (option host_sets; 0 = by frame size).  Forced here on small ragged frames:
