@@ -45,7 +45,11 @@ enum { RTX_PAT_PLAIN = 0, RTX_PAT_STRIPES = 1, RTX_PAT_RINGS = 2, RTX_PAT_CHECKE
 
 /* limits of the bounded per-thread structures (validated by rtx_scene_create) */
 #define RTX_MAX_DEPTH        8    /* reflection/refraction budget; the reference hard-codes 5 (camera.rs:42) */
-#define RTX_MAX_LEVELS      16    /* container nesting depth (groups/CSGs) */
+#define RTX_MAX_LEVELS      62    /* container nesting depth (groups/CSGs); the nested NON-IDENTITY transforms along one path must
+                                     also fit the wave's LDS ray stack (64 KiB: about 20 general transforms, 40 translations) */
+/* CSG roots within the next two limits render with the fast kernels (hit lists and the root's program in LDS); a scene with a
+ * root beyond either renders with the GENERAL CSG kernels: lists of any length and any nesting (what csg.rs:73-91 and
+ * intersections.rs:41-59 build with a Vec), held in a device arena sized by the scene's largest root at rtx_scene_create. */
 #define RTX_MAX_CSG_ENTRIES 16    /* hits collected under one CSG root = 2 x leaf shapes */
 #define RTX_MAX_CSG_NEST     8    /* containers nested inside one CSG root */
 #define RTX_TILE             8    /* 8x8 pixel tile = one wavefront; band = RTX_TILE rows */

@@ -138,7 +138,9 @@ struct Compiler {
     int max_container_level = -1;
     int org_depth = 0, dir_depth = 0, max_org = 0, max_dir = 0;   // LDS slots along the current path / maxima
     bool has_csg = false;
+    bool general = false;            // some CSG root exceeds the bounded (LDS) structures: the scene renders with the general CSG kernels
     int max_csg_entries = 0;
+    int max_clevel = 0;              // deepest container level inside a CSG root
     int err = RTX_OK;
     std::string msg;
 
@@ -296,7 +298,9 @@ struct Compiler {
         if (level > max_container_level) max_container_level = level;
         int entries = 0;
         if (kind == RTX_NODE_GROUP) {
-            if (list && clevel >= RTX_MAX_CSG_NEST) { bad(RTX_E_CAPACITY, "containers nested too deep inside a CSG"); return 0; }
+            if (list && clevel >= RTX_MAX_CSG_NEST) general = true;
+            if (list && clevel > max_clevel) max_clevel = clevel;
+            if (clevel > 255) { bad(RTX_E_CAPACITY, "containers nested deeper than 255 inside a CSG"); return 0; }
             const int b = (int)ops.size();
             ops.push_back(make(node, OPK_GROUP_BEGIN, level, lf, clevel));
             stack.push_back(b);
@@ -316,7 +320,9 @@ struct Compiler {
             has_csg = true;
             const bool root = !list;
             const int cl = root ? 0 : clevel;
-            if (cl >= RTX_MAX_CSG_NEST) { bad(RTX_E_CAPACITY, "containers nested too deep inside a CSG"); return 0; }
+            if (cl >= RTX_MAX_CSG_NEST) general = true;
+            if (cl > max_clevel) max_clevel = cl;
+            if (cl > 255) { bad(RTX_E_CAPACITY, "containers nested deeper than 255 inside a CSG"); return 0; }
             const int f = OPF_LIST | (root ? OPF_ROOT : 0);
             const int b = (int)ops.size();
             OpRec ob = make(node, OPK_CSG_BEGIN, level, f, cl); ob.shape = cop;
@@ -336,8 +342,7 @@ struct Compiler {
             OpRec oe = make(-1, OPK_CSG_END, level, f, cl); oe.shape = cop; ops.push_back(oe);
             ops[b].skip = (int)ops.size();
             if (root && entries > max_csg_entries) max_csg_entries = entries;
-            if (root && entries > RTX_MAX_CSG_ENTRIES)
-                bad(RTX_E_CAPACITY, "CSG root can produce " + std::to_string(entries) + " hits > RTX_MAX_CSG_ENTRIES");
+            if (root && entries > RTX_MAX_CSG_ENTRIES) general = true;
         }
         return entries;
     }
@@ -539,7 +544,8 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static void release_scene_memory(rtx_scene* s) {
     (void)hipSetDevice(s->device);
     for (void** p : {&s->d_ops, &s->d_bodies, &s->d_shapes, &s->d_paths, &s->d_materials, &s->d_lights, &s->d_pairs,
-                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts, &s->d_quad, &s->d_lcull_t, &s->d_quad_t}) {
+                     &s->d_chunks, &s->d_counts, &s->d_lcull, &s->d_lops, &s->d_conts, &s->d_quad, &s->d_lcull_t, &s->d_quad_t,
+                     &s->d_arena, &s->d_arena_bm}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -783,7 +789,35 @@ int rtx_scene_create(rtx_ctx* ctx, const rtx_scene_desc* d, rtx_scene** out) {
     s->dev.n_ops = (int)cc.ops.size(); s->dev.n_shapes = (int)cc.shapes.size(); s->dev.n_lights = d->n_lights;
     s->dev.n_levels = cc.max_container_level + 2;
     s->dev.n_org_slots = cc.max_org + 1; s->dev.n_dir_slots = cc.max_dir + 1;   // slot 0 = the ray being traced
-    s->dev.csg_entries = cc.max_csg_entries; s->dev.has_csg = cc.has_csg ? 1 : 0; s->dev.has_transparency = transp ? 1 : 0; s->dev.has_branching = secondary ? 1 : 0;
+    s->dev.csg_entries = cc.max_csg_entries; s->dev.has_csg = cc.has_csg ? (cc.general ? 2 : 1) : 0; s->dev.has_transparency = transp ? 1 : 0; s->dev.has_branching = secondary ? 1 : 0;
+    s->dev.csg_lds_entries = s->dev.has_csg == 1 ? cc.max_csg_entries : 0;
+    s->dev.csg_prog_lds = s->dev.has_csg == 1 ? prog_max : 0;
+    {
+        // the wave's LDS (ray stack + bounded CSG lists + program + split mailboxes) must fit one workgroup's allocation
+        const size_t lds = (size_t)(s->dev.n_org_slots + s->dev.n_dir_slots) * 192 * sizeof(double) + (((size_t)s->dev.csg_lds_entries * 64 * 12 + 15) & ~(size_t)15) +
+                           (size_t)s->dev.csg_prog_lds * sizeof(uint32_t) + 64 * (3 * sizeof(double) + 2 * sizeof(int));
+        if (lds > RTX_MAX_LDS_BYTES) {
+            rtx_scene_destroy(s);
+            return fail(ctx, RTX_E_CAPACITY, "nested transforms need " + std::to_string(lds) + " bytes of LDS ray stack per wave > " + std::to_string(RTX_MAX_LDS_BYTES));
+        }
+    }
+    if (s->dev.has_csg == 2) {
+        // GENERAL CSG: hit lists of any length and any nesting under a root (the reference's Vec, intersections.rs:41-59) live in
+        // a slot of this arena, claimed by a wave for its lifetime.  More slots than waves can be resident on the chip.
+        const size_t slot = (((size_t)cc.max_csg_entries * 64 * 12 + (size_t)(cc.max_clevel + 1) * 2 * 64 * 4) + 255) & ~(size_t)255;
+        const int words = RTX_ARENA_SLOTS / 32;
+        if (slot > 0x7fffffffull || slot * RTX_ARENA_SLOTS > ((size_t)48 << 30)) {
+            rtx_scene_destroy(s);
+            return fail(ctx, RTX_E_CAPACITY, "CSG root can produce " + std::to_string(cc.max_csg_entries) + " hits: its list arena would exceed 48 GiB");
+        }
+        if (hipMalloc(&s->d_arena, slot * RTX_ARENA_SLOTS) != hipSuccess || hipMalloc(&s->d_arena_bm, words * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(s->d_arena_bm, 0, words * sizeof(unsigned)) != hipSuccess) {
+            rtx_scene_destroy(s);
+            return fail(ctx, RTX_E_DEVICE, "cannot allocate the CSG list arena (" + std::to_string(slot * RTX_ARENA_SLOTS) + " bytes)");
+        }
+        s->dev.arena = (unsigned char*)s->d_arena; s->dev.arena_bitmap = (unsigned*)s->d_arena_bm;
+        s->dev.arena_words = words; s->dev.arena_slot_bytes = (int32_t)slot;
+    }
     *out = s;
     return RTX_OK;
 }
@@ -912,7 +946,8 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
             // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
             // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
-            const bool split = !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES) && lane->side;
+            const bool split = !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES) && lane->side &&
+                               scene->dev.has_csg != 2;      // (the general CSG kernels have no SPLIT variant)
             // PROBE AHEAD.  The probe is a chain of dependent rays on a few thousand waves: ~0.1 ms during which the chip is
             // nearly empty (2.5 % of a 4K frame).  When the caller's stream still holds work — frames are being queued one
             // behind the other — the probe goes to the lane's side stream and into the list set the frame before it is NOT

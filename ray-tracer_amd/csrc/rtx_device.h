@@ -152,7 +152,12 @@ struct SceneDev {
     int32_t n_ops, n_shapes, n_lights, n_levels;   // n_levels = deepest list level + 1
     int32_t csg_prog_max;                          // longest CSG root program in dwords (LDS area of the interpreter)
     int32_t n_org_slots, n_dir_slots;              // LDS ray stack: origin / direction slots needed (rtx_kernel.hip)
-    int32_t has_csg, has_transparency;
+    int32_t has_csg, has_transparency;             // has_csg: 0 none, 1 bounded (lists + program in LDS), 2 general (arena)
+    int32_t csg_lds_entries, csg_prog_lds;         // LDS list entries per lane / program dwords (both 0 unless has_csg == 1)
+    // has_csg == 2: the arena — arena_words * 32 slots of arena_slot_bytes, one claimed per wave for its lifetime through the
+    // bitmap (a set bit = slot in use).  A slot: t[csg_entries][64] doubles, shape[csg_entries][64] u32, marks[csg_levels][2][64] u32
+    unsigned char* arena; unsigned* arena_bitmap;
+    int32_t arena_words, arena_slot_bytes;
     int32_t csg_entries, has_branching;  // has_branching: some material is reflective AND transparent (two children per hit)  // largest number of list entries a CSG root can produce (LDS list area per lane)
 };
 
@@ -202,6 +207,8 @@ struct RenderParams {
 #define RTX_TILE_CLASSES 8
 #define RTX_SPLIT_MAX_TILES 20000   /* launches of at most this many tiles split their most expensive tiles over several waves */
 #endif
+#define RTX_ARENA_SLOTS 4096          /* general CSG mode: list slots (>= waves that can be resident: 256 CUs x 4 SIMDs x 3) */
+#define RTX_MAX_LDS_BYTES 65536       /* LDS one wave (= one workgroup) may ask for */
 #define RTX_CNT_SLOTS 256
 #define RTX_GUARD_UNIT (1ull << 32)   /* the overflow counter's high half counts waves that tripped the SPLIT guard */
 #define RTX_CNT_STRIDE 32

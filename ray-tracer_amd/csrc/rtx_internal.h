@@ -79,6 +79,7 @@ struct rtx_scene {
     SceneDev dev{};
     void* d_ops = nullptr; void* d_bodies = nullptr; void* d_shapes = nullptr; void* d_paths = nullptr;
     void* d_materials = nullptr; void* d_lights = nullptr; void* d_pairs = nullptr;
+    void* d_arena = nullptr; void* d_arena_bm = nullptr;     // general CSG mode: list arena + slot bitmap (rtx_device.h)
     void* d_chunks = nullptr; void* d_counts = nullptr; void* d_lcull = nullptr; void* d_lops = nullptr; void* d_conts = nullptr; void* d_quad = nullptr; void* d_lcull_t = nullptr; void* d_quad_t = nullptr;
 };
 

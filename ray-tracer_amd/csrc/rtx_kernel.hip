@@ -293,7 +293,12 @@ const uint32_t LBIT = 0x80000000u;
 // scratch, the others part of it: written per hit, re-read per light, 4.6 GB of the 4K glass frame's fabric writes); in LDS it
 // costs 4.6 KB per wave, which scenes with several ray-stack slots cannot afford (S3 +22 %, S5 +21 % from the lost occupancy).
 // The launcher therefore picks it per launch: only where the wave's LDS still fits the kernel's occupancy target with it.
-template <bool CSG, bool COUNT, bool PROBE = false, bool SPLIT = false, bool HCTX = false>
+// CSG: 0 = the scene has no CSG; 1 = CSG roots within the bounded structures (per-lane hit lists and the root's program in LDS, at
+// most RTX_MAX_CSG_ENTRIES entries and RTX_MAX_CSG_NEST nested containers per root: the fast kernels); 2 = GENERAL: any number of
+// entries and any nesting under a root — the lists and the per-level marks live in a slot of a global arena that the wave claims
+// for its lifetime (rtx_device.h: arena), the program is read from memory.  Same merge / filter / binary-search insertion
+// (csg.rs:73-136, intersections.rs:41-59); the scene picks the kernel (rtx_api.hip).
+template <int CSG, bool COUNT, bool PROBE = false, bool SPLIT = false, bool HCTX = false>
 __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void trace_shade_kernel(SceneDev sc, CameraDev cam, RenderParams rp,
                                                          uint8_t* __restrict__ rgb,
                                                          int32_t* __restrict__ hit_out,
@@ -476,16 +481,56 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     // CSG hit list (per lane)
     // (in LDS, after the ray slots: entry e of this lane at [e * 64 + lane]; sized by the scene's largest CSG
     // root.  In scratch, every step of the merge loops was a dependent round trip to memory.)
-    double* const lt_ = lds_after + lane;
-    uint32_t* const ls_ = (uint32_t*)(lds_after + sc.csg_entries * 64) + lane;
+    double* lt_ = lds_after + lane;
+    uint32_t* ls_ = (uint32_t*)(lds_after + sc.csg_lds_entries * 64) + lane;
+    uint32_t* marks_ = nullptr;           // CSG == 2: list length at BEGIN / MID per container level: [level][2][64]
+    int arena_slot = -1;
+    if constexpr (CSG == 2) {
+        // ---- claim a slot of the arena (one bit per slot; the arena has more slots than waves can be resident, so a free one
+        // exists; the search is bounded all the same: a wave that finds none reports an overflow and ends, it never spins for ever)
+        if (lane == 0) {
+            unsigned* bm = sc.arena_bitmap;
+            const unsigned W = (unsigned)sc.arena_words;
+            unsigned w = (blockIdx.x * 2654435761u) % W;
+            for (unsigned tries = 0; tries < 64u * W && arena_slot < 0; tries++) {
+                unsigned cur = __hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (~cur != 0u) {
+                    const unsigned bit = (unsigned)__builtin_ctz(~cur);
+                    const unsigned old = atomicOr(&bm[w], 1u << bit);
+                    if (!(old & (1u << bit))) { arena_slot = (int)(w * 32u + bit); break; }
+                    cur = old | (1u << bit);
+                }
+                if (arena_slot < 0) { w = w + 1u == W ? 0u : w + 1u; if ((tries & 63u) == 63u) __builtin_amdgcn_s_sleep(32); }
+            }
+        }
+        arena_slot = __builtin_amdgcn_readfirstlane(arena_slot);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (arena_slot < 0) {
+            if (lane == 0 && !PROBE) {
+                atomicAdd(&counters_base[(blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE + RTX_CNT_OVERFLOW], 64ull);
+                if (rp.sticky) __hip_atomic_store(rp.sticky, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        unsigned char* slot_base = sc.arena + (size_t)arena_slot * (size_t)sc.arena_slot_bytes;
+        lt_ = (double*)slot_base + lane;
+        ls_ = (uint32_t*)(slot_base + (size_t)sc.csg_entries * 64 * 8) + lane;
+        marks_ = (uint32_t*)(slot_base + (size_t)sc.csg_entries * 64 * 12) + lane;
+    }
+    auto arena_release = [&]() {
+        if constexpr (CSG == 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) atomicAnd(&sc.arena_bitmap[arena_slot >> 5], ~(1u << (arena_slot & 31)));
+        }
+    };
 #define lt(i) lt_[(i) * 64]
 #define ls(i) ls_[(i) * 64]
     // split mailboxes (after the CSG lists): colour [3][64] indexed by the SENDER's lane + a posted flag per lane.
     // A lane posts at most once (then it retires), so one box per lane is enough for all levels.
     // mb_state: 0 free, 1 a task is running on this lane, 2 its colour is posted and not yet taken
     // the program of the CSG root being walked (after the lists; 16-byte aligned), then the split mailboxes
-    uint32_t* const prog_lds = (uint32_t*)(lds_after + ((sc.csg_entries * 64 * 12 + 15) / 16) * 2);
-    volatile double* const mb_ = (volatile double*)(prog_lds + sc.csg_prog_max);
+    uint32_t* const prog_lds = (uint32_t*)(lds_after + ((sc.csg_lds_entries * 64 * 12 + 15) / 16) * 2);
+    volatile double* const mb_ = (volatile double*)(prog_lds + sc.csg_prog_lds);
     volatile int* const mb_state = (volatile int*)(mb_ + 3 * 64);
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
@@ -534,7 +579,12 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         int alive = (mode != MODE_DONE) ? 0 : -1;   // deepest list level the lane takes part in
         bool decided = false;             // shadow ray already answered (world.rs:203-206)
         int cnt = 0;                      // CSG list length
-        uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel
+        uint64_t starts = 0, mids = 0;    // 8-bit fields per clevel (CSG == 2: in the arena instead, any number of levels)
+        auto set_start = [&](int cl, int v) { if constexpr (CSG == 2) marks_[cl * 128] = (uint32_t)v; else starts = (starts & ~(0xffull << (cl * 8))) | ((uint64_t)v << (cl * 8)); };
+        auto set_mid = [&](int cl, int v) { if constexpr (CSG == 2) marks_[cl * 128 + 64] = (uint32_t)v; else mids = (mids & ~(0xffull << (cl * 8))) | ((uint64_t)v << (cl * 8)); };
+        auto get_start = [&](int cl) -> int { if constexpr (CSG == 2) return (int)marks_[cl * 128]; else return (int)((starts >> (cl * 8)) & 0xff); };
+        auto get_mid = [&](int cl) -> int { if constexpr (CSG == 2) return (int)marks_[cl * 128 + 64]; else return (int)((mids >> (cl * 8)) & 0xff); };
+        const int list_cap = CSG == 2 ? sc.csg_entries : RTX_MAX_CSG_ENTRIES;
         // (wave-uniform where the kinds take turns: the early-out tests and the container bookkeeping below become scalar branches)
         const bool is_shadow = LOCKSTEP ? !phaseR : mode == MODE_SHADOW;
 
@@ -615,7 +665,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         // of two or three dependent scalar round trips per op.  `cur` / resume_at are dword offsets into the program.
         auto interpret = [&](const int poff, const int plen) {
         TMI(tm_other);
-        {
+        const uint32_t* const prog = CSG == 2 ? sc.csg_prog + poff : prog_lds;
+        if constexpr (CSG != 2) {
             typedef uint32_t U4 __attribute__((ext_vector_type(4)));
             const U4* src = (const U4*)(sc.csg_prog + poff);
             U4* dst = (U4*)prog_lds;
@@ -634,7 +685,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                 cur = __builtin_amdgcn_readfirstlane(wave_min(resume_at));   // keep the offset scalar
                 continue;
             }
-            const uint32_t* rec = prog_lds + cur;
+            const uint32_t* rec = prog + cur;
             const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[0]);
             const int kind = OPH_KIND(info);
             const int level = OPH_LEVEL(info);
@@ -690,7 +741,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             if (slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, t0, t1)) k = 2;
                         }
                         // (every op under a CSG root goes to the per-lane list, in program order)
-                        if (cnt + k > RTX_MAX_CSG_ENTRIES) { overflow = 1; k = 0; }
+                        if (cnt + k > list_cap) { overflow = 1; k = 0; }
                         if (k >= 1) { lt(cnt) = t0; ls(cnt) = (uint32_t)idx; cnt++; }
                         if (k == 2) { lt(cnt) = t1; ls(cnt) = (uint32_t)idx; cnt++; }
                     }
@@ -738,18 +789,15 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                         // the children (level + 1) walk in this node's space
                         po = lo; pd = ld;
                         enter_level(level, xf, pass);
-                        if (pass) {
-                            const int sh = OPH_CLEVEL(info) * 8;
-                            starts = (starts & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
-                        }
+                        if (pass) set_start(OPH_CLEVEL(info), cnt);
                     }
                 }
                 TMI(tm_body);
             } else {
                 // ================= CSG_MID / CSG_END / GROUP_END: list work of the lanes that are in
-                const int sh = OPH_CLEVEL(info) * 8;
+                const int cl = OPH_CLEVEL(info);
                 if (kind == OPK_CSG_MID) {
-                    if (active) mids = (mids & ~(0xffull << sh)) | ((uint64_t)cnt << sh);
+                    if (active) set_mid(cl, cnt);
                 } else {
                     // The merge / filter of csg.rs:83-121 on the lanes' LDS lists is a chain of ~60 dependent LDS round trips
                     // per END op when done in place.  FAST PATH: segments of at most four entries (two children with two hits
@@ -757,7 +805,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     // It is taken when EVERY participating lane's segment is that short and no lane has two equal t after
                     // the sort (the reference re-inserts survivors by binary search, intersections.rs:41-47, whose result
                     // differs from appending only among equal keys); otherwise all lanes take the in-place code below.
-                    const int s0w = (int)((starts >> sh) & 0xff);
+                    const int s0w = active ? get_start(cl) : 0;
                     const int lenw = cnt - s0w;
                     bool fast = !__any(active && lenw > 4);
                     double ft0 = INF, ft1 = INF, ft2 = INF, ft3 = INF; uint32_t fi0 = 0, fi1 = 0, fi2 = 0, fi3 = 0;
@@ -769,7 +817,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             if (lenw > 3) { ft3 = lt(s0w + 3); fi3 = ls(s0w + 3); }
                             if (kind == OPK_CSG_END) {
                                 // csg.rs:83-90: left_shapes membership == "came from the left child"
-                                const int ml = (int)((mids >> sh) & 0xff) - s0w;      // entries of the left child
+                                const int ml = get_mid(cl) - s0w;      // entries of the left child
                                 fi0 = 0 < ml ? (fi0 | LBIT) : (fi0 & ~LBIT); fi1 = 1 < ml ? (fi1 | LBIT) : (fi1 & ~LBIT);
                                 fi2 = 2 < ml ? (fi2 | LBIT) : (fi2 & ~LBIT); fi3 = 3 < ml ? (fi3 | LBIT) : (fi3 & ~LBIT);
                             }
@@ -829,10 +877,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             }
                         }
                     } else if (active) {
-                    const int s0 = (int)((starts >> sh) & 0xff);
+                    const int s0 = get_start(cl);
                     if (kind == OPK_CSG_END) {
                         // csg.rs:83-90: left_shapes membership == "came from the left child"
-                        const int m0 = (int)((mids >> sh) & 0xff);
+                        const int m0 = get_mid(cl);
                         for (int i = s0; i < cnt; i++) ls(i) = (i < m0) ? (ls(i) | LBIT) : (ls(i) & ~LBIT);
                     }
                     // stable sort of the concatenated child lists (intersections.rs:56-59)
@@ -1593,6 +1641,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         atomicAdd(&counters[RTX_CNT_EV0 + 23], tm_light);
     }
 #endif
+    arena_release();
     if (PROBE) {
         // probe launch: the rays this tile's centre pixel needed at the reduced depth -> cost class of the tile;
         // one list append per wave and class (wave-aggregated atomic)
@@ -1683,21 +1732,28 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
     if (blocks <= 0) return hipSuccess;
     const bool split = !rp->probe && rp->use_lists && rp->split_cap > 0 && rp->split_launch;
     if (split) blocks = rp->split_cap << RTX_SPLIT_BITS;
-    size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_entries * 64 * 12 + 15) & ~(size_t)15) +
-                 (size_t)sc->csg_prog_max * sizeof(uint32_t);
+    size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_lds_entries * 64 * 12 + 15) & ~(size_t)15) +
+                 (size_t)sc->csg_prog_lds * sizeof(uint32_t);
     if (split) lds += 64 * (3 * sizeof(double) + 2 * sizeof(int));
     // hit context in LDS (template flag HCTX): only if the wave's LDS still fits the occupancy the kernel is built for
     // (4 waves per SIMD = 16 per CU of 160 KB without CSG, 3 = 12 with; 256 bytes of slack per wave for the allocation granule)
     const size_t hctx_bytes = 8 + 9 * 64 * sizeof(double);
     const size_t waves_cu = 4 * (size_t)(sc->has_csg ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES);
-    const bool hctx = rp->hctx >= 0 ? rp->hctx != 0 : (lds + hctx_bytes + 256) * waves_cu <= (size_t)160 * 1024;
+    const bool general = sc->has_csg == 2;       // (the general CSG kernels are built without SPLIT and HCTX variants)
+    if (general && split) return hipErrorInvalidValue;
+    const bool hctx = !general && (rp->hctx >= 0 ? rp->hctx != 0 : (lds + hctx_bytes + 256) * waves_cu <= (size_t)160 * 1024);
     if (hctx) lds += hctx_bytes;
     dim3 grid(blocks), block(64);
     const bool csg = sc->has_csg != 0;
     const bool count = count_events != 0;
 #define RTX_LAUNCH(C, N, P, S, H) hipLaunchKernelGGL((trace_shade_kernel<C, N, P, S, H>), grid, block, lds, stream, *sc, *cam, *rp, rgb, hit, counters)
 #define RTX_PICK_H(C, N, P, S) do { if (hctx) RTX_LAUNCH(C, N, P, S, true); else RTX_LAUNCH(C, N, P, S, false); } while (0)
-#define RTX_PICK_C(N, P, S) do { if (csg) RTX_PICK_H(true, N, P, S); else RTX_PICK_H(false, N, P, S); } while (0)
+#define RTX_PICK_C(N, P, S) do { if (csg) RTX_PICK_H(1, N, P, S); else RTX_PICK_H(0, N, P, S); } while (0)
+    if (general) {
+        if (rp->probe) RTX_LAUNCH(2, false, true, false, false);
+        else if (count) RTX_LAUNCH(2, true, false, false, false);
+        else RTX_LAUNCH(2, false, false, false, false);
+    } else
     if (rp->probe) RTX_PICK_C(false, true, false);
     else if (split) { if (count) RTX_PICK_C(true, false, true); else RTX_PICK_C(false, false, true); }
     else { if (count) RTX_PICK_C(true, false, false); else RTX_PICK_C(false, false, false); }

@@ -53,13 +53,14 @@ def _shape(rng, n_mats, small=False, planes=True):
     return ("shape", kind, int(rng.integers(0, n_mats)), ops)
 
 
-def _csg(rng, n_mats, budget, depth):
-    """budget = [leaf shapes left, containers left] under the CSG root (kernel limits: 8 / 8)."""
+def _csg(rng, n_mats, budget, depth, max_depth=3, p_nest=0.2):
+    """budget = [leaf shapes left, containers left] under the CSG root (limits of the fast kernels: 8 / 8; plan(big_csg=True) asks
+    for roots beyond them, which render with the general CSG kernels)."""
     def operand():
         r = rng.random()
-        if r < 0.2 and budget[0] >= 2 and budget[1] >= 1 and depth < 3:
+        if r < p_nest and budget[0] >= 2 and budget[1] >= 1 and depth < max_depth:
             budget[1] -= 1
-            return _csg(rng, n_mats, budget, depth + 1)
+            return _csg(rng, n_mats, budget, depth + 1, max_depth, p_nest)
         if r < 0.4 and budget[1] >= 1:
             budget[1] -= 1
             kids = []
@@ -92,7 +93,7 @@ def _group(rng, n_mats, depth):
     return ("group", _ops(rng, 2.0, 0.6, 1.4), kids)
 
 
-def plan(rng, width=64, height=48):
+def plan(rng, width=64, height=48, big_csg=False):
     n_mats = int(rng.integers(2, 7))
     roots = []
     if rng.random() < 0.8:
@@ -100,6 +101,10 @@ def plan(rng, width=64, height=48):
     for _ in range(int(rng.integers(1, 9))):
         r = rng.random()
         roots.append(_group(rng, n_mats, 0) if r < 0.35 else _csg(rng, n_mats, [7, 7], 0) if r < 0.55 else _shape(rng, n_mats))
+    if big_csg:
+        # CSG roots beyond the fast kernels' bounds: up to 40 leaf shapes, containers nested up to 14 deep under a root
+        for _ in range(int(rng.integers(1, 3))):
+            roots.append(_csg(rng, n_mats, [int(rng.integers(9, 41)), 40], 0, max_depth=14, p_nest=0.75))
     a, rad = float(rng.uniform(0, 2 * math.pi)), float(rng.uniform(6, 14))
     return dict(materials=[_material(rng) for _ in range(n_mats)],
                 lights=[([float(rng.uniform(-10, 10)), float(rng.uniform(4, 12)), float(rng.uniform(-10, -2))], [float(rng.uniform(0.3, 1))] * 3)

@@ -9,7 +9,7 @@ bad = skipped = ties = tie_scenes = tie_mis = n = 0
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     rng = np.random.default_rng((int(sys.argv[2]) if len(sys.argv) > 2 else 5000) + seed)
     for i in range(150):
-        p = fuzz_api.plan(rng, int(rng.integers(8, 120)), int(rng.integers(8, 90)))
+        p = fuzz_api.plan(rng, int(rng.integers(8, 120)), int(rng.integers(8, 90)), big_csg=(i % 3 == 2))   # every third: general CSG kernels
         depth = (5, 0, 1, 2, 3, 8, 7, 4)[i % 8]
         pw, pc = fuzz_api.build(rtx.API, p)
         try:

@@ -424,9 +424,11 @@ def test_randomized_api_scene_graphs_parity(ctx):
     import rtapi
     import rtx
     rng = np.random.default_rng(20261112)
+    rng_big = np.random.default_rng(20261113)
     done = px = ties = tie_mis = 0
-    for i in range(40):
-        p = fuzz_api.plan(rng)
+    for i in range(56):
+        # the last 16: with CSG roots beyond the fast kernels' bounds (up to 40 leaves, nesting up to 14: general CSG kernels)
+        p = fuzz_api.plan(rng) if i < 40 else fuzz_api.plan(rng_big, big_csg=True)
         depth = (5, 0, 2, 8)[i % 4]
         pw, pc = fuzz_api.build(rtx.API, p)
         try:
@@ -452,31 +454,56 @@ def test_randomized_api_scene_graphs_parity(ctx):
         fast = ctx.render(pw, pc, depth)
         assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), i
         done += 1
-    assert done >= 30
+    assert done >= 46
     print("randomized scene graphs: %d scenes, %d pixels, %d tie pixels, %d id mismatches inside them" % (done, px, ties, tie_mis))
     assert ties <= 0.03 * px and tie_mis <= 0.02 * max(ties, 1) + 2, (ties, px, tie_mis)
 
 
 def test_kernel_limits_are_reported_not_truncated(ctx):
-    """The bounded structures of the kernel (include/rtx.h: RTX_MAX_CSG_ENTRIES, RTX_MAX_CSG_NEST, RTX_MAX_LEVELS) and the
-    affine-only rule are validated when the scene is created: a scene beyond them is an error code, never a silently
-    wrong image; a scene exactly at a limit renders and matches the oracle."""
+    """The bounded structures of the FAST kernels (include/rtx.h: RTX_MAX_CSG_ENTRIES, RTX_MAX_CSG_NEST) no longer bound the
+    scenes: a CSG root beyond them renders with the general CSG kernels (lists of any length and nesting in a device arena —
+    what csg.rs:73-91 / intersections.rs:41-59 build with a Vec) and must match the oracle like any other scene: ids, colours,
+    ray and event counts.  What remains limited (container nesting of more than RTX_MAX_LEVELS, nested transforms beyond the
+    wave's LDS ray stack, non-affine transforms) is an error code at rtx_scene_create, never a silently wrong image."""
     import ora
     import rtapi
     import rtx
 
     def chain(api, n_leaves):
-        """union(union(...union(s0, s1)..., s_{n-2}), s_{n-1}): n_leaves shapes under one CSG root."""
+        """union(union(...union(s0, s1)..., s_{n-2}), s_{n-1}): n_leaves shapes under one CSG root, n_leaves - 1 nested CSGs."""
         w = api.world_new()
         node = rtapi.shape(w.add_shape(rtapi.SPHERE, None, api.translation(-2.0, 0.5, 0)))
         for k in range(1, n_leaves):
             s = rtapi.shape(w.add_shape(rtapi.SPHERE if k % 2 else rtapi.CUBE, None,
-                                        api.compose([("scale", [0.5, 0.5, 0.5]), ("translate", [-2.0 + 0.55 * k, 0.5, 0.1 * k])])))
+                                        api.compose([("scale", [0.5, 0.5, 0.5]), ("translate", [-2.0 + 4.4 * k / n_leaves, 0.5, 0.8 * k / n_leaves])])))
             node = rtapi.csg(w.add_csg(rtapi.UNION, node, s))
         w.add_object_to_scene(node)
         w.add_light([-5, 8, -8], [1, 1, 1])
         w.build()
         return w, api.camera(96, 48, 1.0, api.view_transform([0, 2, -9], [0, 0.5, 0], [0, 1, 0]))
+
+    def nested_csg(api, depth):
+        """`depth` CSGs inside each other, every one with a transform of its own (a new ray-stack level each), the operators
+        cycling union / difference / intersection, operands alternating sides; glass and mirror materials so that the refractive
+        containers and the secondary rays go through the general lists too."""
+        w = api.world_new()
+        glass = api.material(color=[0.2, 0.3, 0.9], transparency=0.7, reflective=0.3, refractive_index=1.4, diffuse=0.4)
+        node = rtapi.shape(w.add_shape(rtapi.SPHERE, glass, api.scaling(1.2, 1.2, 1.2)))
+        ops = [rtapi.UNION, rtapi.DIFFERENCE, rtapi.UNION, rtapi.INTERSECTION, rtapi.UNION]
+        for k in range(depth):
+            big = ops[k % 5] == rtapi.INTERSECTION
+            s = rtapi.shape(w.add_shape(rtapi.CUBE if k % 2 else rtapi.SPHERE, glass if k % 3 == 0 else None,
+                                        api.compose([("scale", [2.5, 2.5, 2.5] if big else [0.45, 0.6, 0.45]),
+                                                     ("translate", [0, 0, 0] if big else [1.2 * ((k % 4) - 1.5), 0.3 * (k % 3), 0.4 * ((k % 2) - 0.5)])])))
+            xf = api.compose([("rotate-y", 0.05 * (k + 1)), ("translate", [0.02 * k, 0.01, 0])])
+            op = ops[k % 5]
+            node = rtapi.csg(w.add_csg(op, node, s, xf) if (op == rtapi.DIFFERENCE or k % 2) else w.add_csg(op, s, node, xf))
+        w.add_object_to_scene(node)
+        w.add_object_to_scene(rtapi.shape(w.add_shape(rtapi.PLANE, api.material(color=[0.8, 0.8, 0.7], reflective=0.2), api.translation(0, -1.5, 0))))
+        w.add_light([-5, 8, -8], [1, 1, 1])
+        w.add_light([6, 5, -7], [0.4, 0.4, 0.4])
+        w.build()
+        return w, api.camera(96, 64, 1.0, api.view_transform([0, 2, -9], [0, 0.3, 0], [0, 1, 0]))
 
     def nested_groups(api, depth):
         w = api.world_new()
@@ -491,16 +518,27 @@ def test_kernel_limits_are_reported_not_truncated(ctx):
         w.build()
         return w, api.camera(64, 48, 1.0, api.view_transform([0, 1, -6], [0, 0.5, 0], [0, 1, 0]))
 
-    # exactly at the limits: 8 leaf shapes under one CSG root (16 list entries), 16 nested groups
-    for builder, arg in ((chain, 8), (nested_groups, 16)):
+    # at the limits of the fast kernels (8 leaf shapes = 16 list entries under one root; the old nesting limit), past them
+    # (general CSG kernels: 9 and 32 leaves = 8 and 31 nested CSGs, 12 CSGs with transforms inside each other) and deeper groups
+    for builder, arg in ((chain, 8), (nested_groups, 16), (chain, 9), (chain, 32), (nested_csg, 12), (nested_csg, 3), (nested_groups, 17)):
         pw, pc = builder(rtx.API, arg)
         ow, oc = builder(ora.API, arg)
         gpu = ctx.render(pw, pc, 5, flags=rtx.F_COUNT_EVENTS | rtx.F_NO_SHADOW_EARLY_OUT)
         cpu = ora.render(ow, oc, 5, threads=8)
-        parity.assert_parity(gpu, cpu, "%s(%d)" % (builder.__name__, arg))
-        assert gpu["stats"].rays == cpu["stats"].rays and (gpu["hit"] >= 0).any()
-    # one past them
-    for builder, arg in ((chain, 9), (nested_groups, 17)):
+        what = "%s(%d)" % (builder.__name__, arg)
+        parity.assert_parity(gpu, cpu, what)
+        gs, cs = gpu["stats"], cpu["stats"]
+        assert (gs.rays_primary, gs.rays_shadow, gs.rays_secondary) == (cs.rays_primary, cs.rays_shadow, cs.rays_secondary), what
+        assert (gpu["hit"] >= 0).any(), what
+        ge, ce = gs.events(), cs.events()
+        assert {k: ge[k] for k in rtapi.REF_EVENTS if k != "pow"} == {k: ce[k] for k in rtapi.REF_EVENTS if k != "pow"}, what
+        # the product mode (early-outs, tight spheres, tile lists forced on) renders the same bytes
+        ctx.options(lpt=1)
+        fast = ctx.render(pw, pc, 5)
+        ctx.options(lpt=-1)
+        assert np.array_equal(fast["rgb"], gpu["rgb"]) and np.array_equal(fast["hit"], gpu["hit"]), what
+    # what is still limited is reported: nesting beyond RTX_MAX_LEVELS, nested general transforms beyond the LDS ray stack
+    for builder, arg in ((nested_groups, 63), (nested_groups, 30)):
         pw, pc = builder(rtx.API, arg)
         with pytest.raises(rtx.RtxError) as e:
             ctx.render(pw, pc, 5)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../ray-tracer_amd" && /opt/rocm/bin/hipcc -O3 -std=c++17 -fP
 import re, sys
 cur = None
 for line in sys.stdin:
-    m = re.search(r"Function Name: _Z18trace_shade_kernelILb([01])ELb([01])ELb([01])ELb([01])ELb([01])", line)
+    m = re.search(r"Function Name: _Z18trace_shade_kernelILi([012])ELb([01])ELb([01])ELb([01])ELb([01])", line)
     if m:
         cur = "CSG=%s COUNT=%s PROBE=%s SPLIT=%s HCTX=%s" % m.groups(); vals = []
         continue
