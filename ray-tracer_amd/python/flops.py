@@ -95,7 +95,9 @@ def pmc_counters(workload, path=None):
     by_pass = w.get("kernel_ms_by_pass", {})
     ms_f, ms_w = by_pass.get("fetchsz", w.get("kernel_ms")), by_pass.get("write", w.get("kernel_ms"))
     hbm_gbps = (c["FETCH_SIZE"] * 1024 / (ms_f * 1e-3) + c["WRITE_SIZE"] * 1024 / (ms_w * 1e-3)) / 1e9 if ms_f and ms_w else None
-    kres = rec.get("kres", {}).get("CSG=%d COUNT=0 PROBE=0 SPLIT=0" % (1 if workload == "S5" else 0), {})
+    # the instantiation the timed launch of this workload runs (S5: bounded-CSG kernel; S2 / S4: hit context in LDS, S3 / S5: in registers)
+    key = "CSG=%d COUNT=0 PROBE=0 SPLIT=0" % (1 if workload == "S5" else 0)
+    kres = rec.get("kres", {}).get(key + " HCTX=%d" % (1 if workload in ("S2", "S4") else 0), rec.get("kres", {}).get(key, {}))
     return {"lane_util": lane_util, "hbm_gbps": hbm_gbps,
             "spilled_vgprs": kres.get("VGPRs Spill"), "spilled_sgprs": kres.get("SGPRs Spill"),"file": os.path.basename(path), "git_rev": rec.get("git_rev"), "kernel_ms": w.get("kernel_ms"),
             "traffic_bytes": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
