@@ -23,6 +23,7 @@
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
                                              int count_events, hipStream_t stream);
+extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, hipStream_t stream);
 
 __global__ void debug_math_kernel(int op, long long n, const double* a, const double* b, double* out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,6 +550,7 @@ static void release_scene_memory(rtx_scene* s) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    for (rtx_cost_entry& e : s->cost) { if (e.d_cost) (void)hipFree(e.d_cost); e = rtx_cost_entry(); }
 }
 
 int rtx_init(int device, rtx_ctx** out) {
@@ -570,6 +572,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.stream_lpt = env_int("RTX_STREAM_LPT", -1);
     c->opt.probe_ahead = env_int("RTX_PROBE_AHEAD", -1);
     c->opt.hctx = env_int("RTX_HCTX", -1);
+    c->opt.cost_feedback = env_int("RTX_COST_FEEDBACK", -1);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -653,8 +656,17 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "stream_lpt") c->opt.stream_lpt = value;
     else if (n == "probe_ahead") c->opt.probe_ahead = value;
     else if (n == "hctx") c->opt.hctx = value;
+    else if (n == "cost_feedback") c->opt.cost_feedback = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
+}
+
+int64_t rtx_debug_counter(const rtx_ctx* c, const char* name) {
+    if (!c || !name) return -1;
+    const std::string n(name);
+    if (n == "probe_launches") return c->n_probe_launches;
+    if (n == "classify_launches") return c->n_classify_launches;
+    return -1;
 }
 
 int rtx_ctx_poll(rtx_ctx* c, int wait) {
@@ -956,7 +968,42 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             // runs where it used to.  A frame queued on an idle stream keeps the in-stream probe (no event hop in its latency).
             // (Callers that overlap whole frames themselves — the render lanes of rtx_render_gathered and rtx_render's band sets,
             // which pass RTX_F_INTERNAL_NO_SPLIT, and the lanes of rtx_render_batch — gain nothing from it: measured 0 to -4 %.)
-            bool ahead = !split && !(flags & (RTX_F_INTERNAL_NO_SPLIT | RTX_F_INTERNAL_NO_AHEAD)) && may_allocate && lane->side && ctx->opt.probe_ahead != 0;
+            // TILE-COST FEEDBACK.  Every frame launch leaves per tile the traced rays of its busiest pixel (rp.tile_cost).  A frame of
+            // the same VIEW of the scene (same image size, bands and depth budget, camera equal or close) files its tiles by those
+            // measured costs with a classify launch (one thread per tile, microseconds) instead of tracing probe rays: the order is
+            // the one exact costs give (2-3 % better than the probe's estimate) and the probe launch — a chain of
+            // dependent rays on a nearly empty chip — is gone.  First frame of a view, a camera jump, or every 32nd frame while
+            // tiles are split (a split tile cannot measure its own unsplit cost): the probe, which also seeds the costs.
+            rtx_cost_entry* ce = nullptr;
+            bool reuse = false;
+            if (may_allocate && ctx->opt.cost_feedback != 0) {
+                rtx_cost_entry* lru = &scene->cost[0];
+                for (rtx_cost_entry& e : scene->cost) {
+                    if (e.d_cost && e.hsize == cam->hsize && e.vsize == cam->vsize && e.band_first == bands.first && e.band_stride == bands.stride &&
+                        e.max_depth == max_depth) { ce = &e; break; }
+                    if (e.used < lru->used) lru = &e;
+                }
+                if (!ce) {
+                    ce = lru;
+                    if (ce->cap < (size_t)n_tiles) {
+                        if (ce->d_cost) (void)hipFree(ce->d_cost);         // (hipFree waits for the device: no launch still uses it)
+                        ce->d_cost = nullptr; ce->cap = 0;
+                        HIPCHK(ctx, hipMalloc((void**)&ce->d_cost, (size_t)n_tiles * sizeof(int32_t)));
+                        ce->cap = n_tiles;
+                    }
+                    ce->hsize = cam->hsize; ce->vsize = cam->vsize; ce->band_first = bands.first; ce->band_stride = bands.stride; ce->max_depth = max_depth;
+                    ce->valid = false; ce->age = 0;
+                }
+                ce->used = ++scene->cost_clock;
+                bool close = ce->valid;
+                for (int k = 0; k < 16 && close; k++) close = std::fabs(ce->cam_inverse[k] - cam->inverse[k]) <= 0.05;    // (false on NaN)
+                reuse = close && !(split && ce->age >= 32);
+                std::memcpy(ce->cam_inverse, cam->inverse, sizeof ce->cam_inverse);
+                ce->age = reuse ? ce->age + 1 : 0;
+                ce->valid = true;
+                rp.tile_cost = ce->d_cost;
+            }
+            bool ahead = !split && !reuse && !(flags & (RTX_F_INTERNAL_NO_SPLIT | RTX_F_INTERNAL_NO_AHEAD)) && may_allocate && lane->side && ctx->opt.probe_ahead != 0;
             if (ahead && ctx->opt.probe_ahead < 0) ahead = hipStreamQuery(st) == hipErrorNotReady;
             (void)hipGetLastError();
             int32_t* lists = lane->d_lists; int32_t* counts = lane->d_tile_counts;
@@ -994,7 +1041,13 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             pp.probe = 1; pp.max_depth = ctx->opt.probe_depth;   // (1, 2, 3 measured: 2 is best)
             if (pp.max_depth < 0) pp.max_depth = 0;
             if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lists; pp.tile_counts = counts;
-            HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, pst));
+            if (reuse) {
+                HIPCHK(ctx, rtx_launch_classify_tiles(ce->d_cost, n_tiles, lists, counts, pst));
+                ctx->n_classify_launches++;
+            } else {
+                HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, pst));
+                ctx->n_probe_launches++;
+            }
             rp.use_lists = 1; rp.tile_lists = lists; rp.tile_counts = counts;
             if (ahead) {
                 HIPCHK(ctx, hipEventRecord(lane->ev_probe[set], pst));

@@ -189,6 +189,10 @@ struct RenderParams {
     unsigned long long* sticky;   // device-visible host word: set non-zero when this launch reports an overflow (asynchronous renders)
     int32_t tile_mul;         // block b renders tile (b * tile_mul) mod n_tiles: coprime with n_tiles, spreads heavy image
                               //   regions over the whole dispatch instead of leaving them to the tail
+    // tile-cost feedback (rtx_api.hip): every frame launch leaves, per tile, the traced rays of the tile's busiest pixel (the
+    // probe launch: its estimate of that figure); the next frame of the same view files its tiles by these costs with a
+    // classify launch instead of a probe launch
+    int32_t* tile_cost;       // n_tiles entries, or NULL
     int32_t hctx;             // hit context in LDS (rtx_kernel.hip, template flag HCTX): -1 = where the LDS budget allows, 0 / 1 = forced
 };
 
@@ -209,6 +213,9 @@ struct RenderParams {
 #endif
 #define RTX_ARENA_SLOTS 4096          /* general CSG mode: list slots (>= waves that can be resident: 256 CUs x 4 SIMDs x 3) */
 #define RTX_MAX_LDS_BYTES 65536       /* LDS one wave (= one workgroup) may ask for */
+// cost classes of the tile-order lists: class k holds the tiles whose busiest pixel traces [RTX_CLASS_LO(k), RTX_CLASS_LO(k+1)) rays
+#define RTX_CLASS_OF_COST(c) ((c) < 4 ? 0 : (c) < 8 ? 1 : (c) < 16 ? 2 : (c) < 32 ? 3 : (c) < 48 ? 4 : (c) < 64 ? 5 : (c) < 96 ? 6 : 7)
+#define RTX_COST_OF_CLASS(k) ((k) == 0 ? 2 : (k) == 1 ? 6 : (k) == 2 ? 12 : (k) == 3 ? 24 : (k) == 4 ? 40 : (k) == 5 ? 56 : (k) == 6 ? 80 : 120)
 #define RTX_CNT_SLOTS 256
 #define RTX_GUARD_UNIT (1ull << 32)   /* the overflow counter's high half counts waves that tripped the SPLIT guard */
 #define RTX_CNT_STRIDE 32

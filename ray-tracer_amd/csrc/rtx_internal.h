@@ -22,6 +22,8 @@ struct rtx_opts {
                              // caller's stream is busy, 0 = never, 1 = always
     int stream_lpt = -1;     // streaming callers of rtx_render_gathered keep the tile-order probe: -1 = by dispatch length, 0 / 1 = forced
     int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
+    int cost_feedback = -1;  // tile order from the costs the previous frame of the same view measured, instead of a probe launch:
+                             // -1 / 1 = on, 0 = off (always probe)
     int hctx = -1;           // hit context in LDS instead of registers: -1 = where the wave's LDS budget allows (rtx_kernel.hip), 0 / 1 = forced
     int pipeline = 3;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
                              // 2..4; below 2 = every frame on the caller's stream)
@@ -69,11 +71,26 @@ struct rtx_ctx {
     unsigned char* d_scratch = nullptr;
     Lane noalloc_lane;                                                       // lists / counts inside d_scratch, side stream shared with lanes[0]
     rtx_opts opt;
+    long long n_probe_launches = 0, n_classify_launches = 0;                 // diagnostics (rtx_debug_counter)
     std::vector<rtx_scene*> scenes;                                          // live scenes (rtx_shutdown releases their device memory)
     std::string err;
 };
 
+// Tile-cost feedback (rtx_api.hip, enqueue_render): what the last frame of one VIEW of a scene (image size, band selection, depth
+// budget, camera) measured per tile; the next frame of the same view orders its tiles by it instead of probing.
+struct rtx_cost_entry {
+    int hsize = 0, vsize = 0, band_first = 0, band_stride = 0, max_depth = 0;
+    double cam_inverse[16] = {};
+    int32_t* d_cost = nullptr; size_t cap = 0;
+    bool valid = false;          // d_cost holds the costs of a frame of this view (queued or done)
+    int age = 0;                 // frames since the last probe launch of this view
+    unsigned long long used = 0; // for eviction: context-wide use counter at the last use
+};
+
 struct rtx_scene {
+    static constexpr int kCostEntries = 16;
+    mutable rtx_cost_entry cost[kCostEntries];
+    mutable unsigned long long cost_clock = 0;
     rtx_ctx* ctx = nullptr;      // nullptr once the context is gone (rtx_shutdown released the device memory)
     int device = 0;
     SceneDev dev{};

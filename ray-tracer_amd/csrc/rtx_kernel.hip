@@ -1667,6 +1667,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         cls = cls > RTX_TILE_CLASSES - 1 ? RTX_TILE_CLASSES - 1 : cls;
         if (!pvalid) cls = -1;
         const int t = pbl * rp.tiles_x + ptx;
+        if (pvalid && rp.tile_cost) rp.tile_cost[t] = RTX_COST_OF_CLASS(cls);     // an estimate, until a frame launch measures the tile
         for (int k = 0; k < RTX_TILE_CLASSES; k++) {
             const unsigned long long m = __ballot(cls == k);
             if (m == 0) continue;
@@ -1698,6 +1699,14 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         if (px < cam.hsize && py < cam.vsize) hit_out[(size_t)row * cam.hsize + px] = (int)(n_radiance + n_shadow - n_skipped);
     }
 #endif
+    // ---- tile-cost feedback: the traced rays of the tile's busiest pixel, for the next frame's tile order (split tiles keep
+    // their last figure: their pixels' rays are spread over helper lanes)
+    if (!SPLIT && rp.tile_cost) {
+        int c = (int)(n_radiance + n_shadow - n_skipped);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(c, o, 64); c = w > c ? w : c; }
+        if (lane == 0) rp.tile_cost[tile] = c;
+    }
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow), t3 = wave_sum(n_skipped);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
@@ -1760,5 +1769,31 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
 #undef RTX_PICK_C
 #undef RTX_PICK_H
 #undef RTX_LAUNCH
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- tile-cost feedback: classify launch (called by rtx_api.hip)
+// Files every tile of the launch under the class of its cost (rtx_device.h: RTX_CLASS_OF_COST) — what the probe launch does
+// from its own estimate, here from the costs the previous frame of the same view measured.  One thread per tile, one
+// wave-aggregated append per wave and class.
+__global__ void classify_tiles_kernel(const int32_t* __restrict__ cost, int n_tiles, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = (int)(threadIdx.x & 63);
+    const int cls = t < n_tiles ? RTX_CLASS_OF_COST(cost[t]) : -1;
+    for (int k = 0; k < RTX_TILE_CLASSES; k++) {
+        const unsigned long long m = __ballot(cls == k);
+        if (m == 0) continue;
+        const int leader = (int)__builtin_ctzll(m);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counts[k], (int)__builtin_popcountll(m));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (cls == k) lists[(size_t)k * n_tiles + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+    }
+}
+
+extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, hipStream_t stream) {
+    static_assert(RTX_TILE_CLASSES == 8, "RTX_CLASS_OF_COST files into 8 classes");
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(classify_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, cost, n_tiles, lists, counts);
     return hipGetLastError();
 }

@@ -791,6 +791,57 @@ def test_hit_context_in_lds_does_not_change_the_image(ctx, name, w, h):
 
 
 
+def test_tile_cost_feedback_orders_tiles_without_changing_the_image(ctx):
+    """Tile-cost feedback (rtx_api.hip): every frame launch leaves per tile the traced rays of its busiest pixel, and the next
+    frame of the same view (size, bands, depth budget; camera equal or close) files its tiles by those costs with a classify
+    launch instead of a probe launch.  Scheduling only: a sequence of frames — same camera, a slightly moved camera, a camera
+    jump, another size, band sets, split tiles forced on — must equal the renders with the feedback off byte for byte (ids
+    and ray counts too), and the launch counters must show probes only where a view is new, jumps, or is due for a refresh."""
+    import rtx
+    def counters():
+        return (rtx.LIB.rtx_debug_counter(ctx.h, b"probe_launches"), rtx.LIB.rtx_debug_counter(ctx.h, b"classify_launches"))
+    pw, pc = rtx.load_yaml(parity.scene_text("S4", 333, 171))
+    near = rtx.API.camera(333, 171, 1.0471975511965976, rtx.API.view_transform([0.02, 3.21, -10.99], [0, 1.2, 0], [0, 1, 0]))
+    far = rtx.API.camera(333, 171, 1.0471975511965976, rtx.API.view_transform([6, 2, -9], [0, 1, 0], [0, 1, 0]))
+    _, other = rtx.load_yaml(parity.scene_text("S4", 200, 301))
+    sc = ctx.scene(pw)
+    try:
+        ctx.options(lpt=1, split=0, cost_feedback=0)
+        want = {k: sc.render(c, 5) for k, c in (("a", pc[0]), ("near", near), ("far", far), ("other", other[0]))}
+        want_bands = [sc.render(pc[0], 5, bands=(g, 3), flags=rtx.F_BANDS_COMPACT) for g in range(3)]
+        ctx.options(cost_feedback=-1)
+        def same(got, w):
+            assert np.array_equal(got["rgb"], w["rgb"]) and np.array_equal(got["hit"], w["hit"]) and got["stats"].rays == w["stats"].rays
+        p0, c0 = counters()
+        for k in range(3):
+            same(sc.render(pc[0], 5), want["a"])
+        assert counters() == (p0 + 1, c0 + 2)                     # first frame of the view probes, the next two classify
+        same(sc.render(near, 5), want["near"])                    # a camera close to the last one: the costs still order the tiles
+        assert counters() == (p0 + 1, c0 + 3)
+        same(sc.render(far, 5), want["far"])                      # a jump: probe
+        assert counters() == (p0 + 2, c0 + 3)
+        same(sc.render(other[0], 5), want["other"])               # another image size: a view of its own
+        same(sc.render(other[0], 5), want["other"])
+        assert counters() == (p0 + 3, c0 + 4)
+        for rep in range(2):                                      # band sets are views of their own (rank r of 3)
+            for g in range(3):
+                same(sc.render(pc[0], 5, bands=(g, 3), flags=rtx.F_BANDS_COMPACT), want_bands[g])
+        assert counters() == (p0 + 6, c0 + 7)
+        # split tiles: the top class comes from the measured costs; a split tile keeps its last figure, refreshed by a probe every 32 frames
+        ctx.options(split=1, split_class=5)
+        p1, c1 = counters()
+        for k in range(36):
+            got = sc.render(far, 5)
+            if k in (0, 1, 35):
+                same(got, want["far"])
+        p2, c2 = counters()
+        assert (p2 - p1, c2 - c1) == (1, 35), (p2 - p1, c2 - c1)
+    finally:
+        ctx.options(lpt=-1, split=-1, split_class=7, cost_feedback=-1)
+        sc.close()
+
+
+
 def test_host_render_in_band_sets_equals_one_launch(ctx):
     """rtx_render of a whole frame into host buffers renders large frames as 2..8 interleaved band sets on two lanes and copies
     each set out while the next ones render (option host_sets; 0 = by frame size).  Forced here on small ragged frames:

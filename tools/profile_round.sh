@@ -14,3 +14,5 @@ for wl in S3 S4 S5; do
   for s in sq sq2 sq3 tcc fetchsz write; do python3 tools/rocpd_summary.py $(find gpurun_out/pmc_${tag}_${wl}_$s -name "*.db" | head -1); done > gpurun_out/${tag}_${wl}_pmc.txt
 done
 python3 tools/pmc_counters.py $tag $rev S3 S4 S5 > gpurun_out/${tag}_counters.json
+# the raw rocprofv3 databases are large (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf gpurun_out/pmc_${tag}_* gpurun_out/${tag}_prof
