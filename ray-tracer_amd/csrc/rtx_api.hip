@@ -23,6 +23,7 @@
 extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev* cam, const RenderParams* rp,
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
                                              int count_events, hipStream_t stream);
+extern "C" hipError_t rtx_launch_reset_counters(unsigned long long* counters, const int32_t* tile_cost, hipStream_t stream);
 extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, hipStream_t stream);
 
 __global__ void debug_math_kernel(int op, long long n, const double* a, const double* b, double* out) {
@@ -919,7 +920,6 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
 
     int ahead_set = -1;                           // list set this frame's launches read: its "launch done" event is recorded at the end
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(d_counters, 0, kCounterWords * sizeof(unsigned long long), st));
     if (ev_begin) HIPCHK(ctx, hipEventRecord(ev_begin, st));
     // ---- expensive tiles first: a probe launch (the centre pixel of every tile, depth budget 2, no image, no
     // counters) files every tile under a cost class; the frame launch walks the classes most expensive first.
@@ -1069,6 +1069,8 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
 #endif
         }
     }
+    // counters to zero (and the address of the tile-cost array into the block's spare word): one small launch on `st`
+    HIPCHK(ctx, rtx_launch_reset_counters(d_counters, rp.tile_cost, st));
     if (rp.split_cap > 0) {
         // fork: the SPLIT launch (expensive tiles, several waves each) goes first, on the lane's side stream; the
         // main launch renders the other tiles beside it and waits for it at the end

@@ -203,6 +203,11 @@ struct RenderParams {
 #define RTX_CNT_EV0 3
 #define RTX_CNT_SKIPPED (3 + 24)   /* shadow rays counted but not traced (light certainly behind the surface) */
 #define RTX_CNT_TOTAL (3 + 24 + 1)
+// Word RTX_CNT_COST_PTR of the FIRST counter slot (a spare word: a slot has RTX_CNT_STRIDE = 32 words, RTX_CNT_TOTAL are counters)
+// carries the address of the tile-cost array of this render, or 0: the frame kernels read it when a wave ends.  (As a kernel
+// argument the pointer would be live — two scalar registers — through the whole kernel, also for scenes that never use it:
+// measured +2 % on the CSG workload.)  The reset launch that zeroes the block writes it.
+#define RTX_CNT_COST_PTR 31
 // The counters are replicated over RTX_CNT_SLOTS slots of RTX_CNT_STRIDE entries (256 bytes, own cache lines);
 // a wave adds into slot (block index mod RTX_CNT_SLOTS) and the host sums the slots.  With ONE set of
 // counters every wave's two ray-count atomics hit the same address and serialise at ~12 ns each: a floor of

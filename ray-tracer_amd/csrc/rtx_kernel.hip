@@ -535,7 +535,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     volatile int* const mb_rem = mb_state + 64;
     if (SPLIT) mb_state[lane] = 0;
     // HCTX: the hit context's LDS area, after everything else: [9][64] doubles
-    double* const hctx = (double*)(((uintptr_t)(SPLIT ? (const volatile void*)(mb_rem + 64) : (const volatile void*)mb_) + 7) & ~(uintptr_t)7) + lane;
+    // (its offset is computed from the LDS base with integers, so the pointer provably stays an LDS pointer: ds_* instead of flat_*)
+    const unsigned hctx_off = ((unsigned)(sc.n_org_slots + sc.n_dir_slots) * LDS_HALF_DOUBLES * 8u + (((unsigned)sc.csg_lds_entries * 64u * 12u + 15u) & ~15u) +
+                               (unsigned)sc.csg_prog_lds * 4u + (SPLIT ? 64u * 32u : 0u) + 7u) & ~7u;
+    double* const hctx = (double*)((char*)lds_rays + hctx_off) + lane;
 
     bool phaseR = false;                  // the kind of ray the last iteration traced (see the top of the loop)
     bool guard_hit = false;
@@ -805,7 +808,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     // It is taken when EVERY participating lane's segment is that short and no lane has two equal t after
                     // the sort (the reference re-inserts survivors by binary search, intersections.rs:41-47, whose result
                     // differs from appending only among equal keys); otherwise all lanes take the in-place code below.
-                    const int s0w = active ? get_start(cl) : 0;
+                    int s0w;
+                    if constexpr (CSG == 2) s0w = active ? get_start(cl) : 0; else s0w = get_start(cl);
                     const int lenw = cnt - s0w;
                     bool fast = !__any(active && lenw > 4);
                     double ft0 = INF, ft1 = INF, ft2 = INF, ft3 = INF; uint32_t fi0 = 0, fi1 = 0, fi2 = 0, fi3 = 0;
@@ -1700,16 +1704,18 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     }
 #endif
     // ---- tile-cost feedback: the traced rays of the tile's busiest pixel, for the next frame's tile order (split tiles keep
-    // their last figure: their pixels' rays are spread over helper lanes)
-    if (!SPLIT && rp.tile_cost) {
-        int c = (int)(n_radiance + n_shadow - n_skipped);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(c, o, 64); c = w > c ? w : c; }
-        if (lane == 0) rp.tile_cost[tile] = c;
-    }
+    // their last figure: their pixels' rays are spread over helper lanes).  The array's address waits in a spare counter word.
+    int32_t* tile_cost = nullptr;
+    if (!SPLIT) tile_cost = (int32_t*)__hip_atomic_load(&counters_base[RTX_CNT_COST_PTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (requested here, used below)
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow), t3 = wave_sum(n_skipped);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
+    if (!SPLIT && tile_cost) {
+        int c = (int)(n_radiance + n_shadow - n_skipped);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(c, o, 64); c = w > c ? w : c; }
+        if (lane == 0) tile_cost[bl * rp.tiles_x + tx] = c;        // (= the launch's tile index, rebuilt from what is live anyway)
+    }
     if (lane == 0) {
         atomicAdd(&counters[RTX_CNT_RADIANCE], (unsigned long long)t0);
         atomicAdd(&counters[RTX_CNT_SHADOW], (unsigned long long)t1);
@@ -1795,5 +1801,17 @@ extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles
     static_assert(RTX_TILE_CLASSES == 8, "RTX_CLASS_OF_COST files into 8 classes");
     if (n_tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(classify_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, cost, n_tiles, lists, counts);
+    return hipGetLastError();
+}
+
+// zeroes one replicated counter block and leaves the tile-cost array's address (or 0) in its spare word (rtx_device.h)
+__global__ void reset_counters_kernel(unsigned long long* counters, unsigned long long cost_ptr) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < RTX_CNT_SLOTS * RTX_CNT_STRIDE) counters[i] = i == RTX_CNT_COST_PTR ? cost_ptr : 0ull;
+}
+
+extern "C" hipError_t rtx_launch_reset_counters(unsigned long long* counters, const int32_t* tile_cost, hipStream_t stream) {
+    hipLaunchKernelGGL(reset_counters_kernel, dim3((RTX_CNT_SLOTS * RTX_CNT_STRIDE + 255) / 256), dim3(256), 0, stream, counters,
+                       (unsigned long long)(uintptr_t)tile_cost);
     return hipGetLastError();
 }

@@ -259,7 +259,9 @@ int comm_render_bands(rtx_comm* c, const rtx_scene* scene, const rtx_camera* cam
             // (the probe still pays for long dispatches: measured on S4 with three frames in flight, tools/pipeline_probe.py,
             // with / without it: 4.14 / 4.36 ms at N = 1, 2.14 / 2.18 at N = 2, 1.17 / 1.15 at N = 4, 0.67 / 0.63 at N = 8)
             const long long share_tiles = (long long)((cam->hsize + RTX_TILE - 1) / RTX_TILE) * (rows_padded(cam->vsize, c->world) / RTX_TILE);
-            const bool keep_probe = ctx->opt.stream_lpt >= 0 ? ctx->opt.stream_lpt != 0 : share_tiles >= 40000;
+            // (with the tile-cost feedback the lists cost a classify launch of microseconds from the second frame of a view on,
+            // not a probe launch: they are kept for short dispatches too)
+            const bool keep_probe = ctx->opt.stream_lpt >= 0 ? ctx->opt.stream_lpt != 0 : (share_tiles >= 40000 || ctx->opt.cost_feedback != 0);
             sched = RTX_F_INTERNAL_NO_SPLIT | (keep_probe ? 0u : RTX_F_INTERNAL_NO_LPT);
         }
         (void)hipGetLastError();
