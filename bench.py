@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--kernel-only", action="store_true",
+                    help="N = 1: only the kernel region (K whole-frame launches through rtx_render_device) — what the rocprofv3 PMC "
+                         "passes profile, so that every dispatch of the frame kernel they average over is one whole frame")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -178,7 +181,7 @@ def main():
     comm, comm_error = None, None
     comm_kind = "rccl"
     torch_gather = False
-    if N == 1 and not force_comm:
+    if N == 1 and not force_comm and not args.kernel_only:
         # N = 1: the same entry point over a one-rank RCCL communicator (no torch.distributed needed: the id stays here).  If
         # RCCL does not come up, the library's loopback communicator (same render lanes, same de-interleave, no ncclAllGather)
         # takes its place and the line says so.
@@ -329,7 +332,7 @@ def main():
                 lat.append(time.perf_counter() - a)
             one = min(lat) * 1000.0
         host_ms = None
-        if N == 1:
+        if N == 1 and not args.kernel_only:
             # what Camera::render (camera.rs:39-54) returns: the frame in HOST memory (pageable, as a caller's Vec would be).
             # The first whole-frame rtx_render of a context takes the one-launch path, the later ones the band sets.
             import numpy as np

@@ -72,7 +72,7 @@ def main():
     if os.path.exists(kres):
         out["kres"] = {}
         for line in open(kres):
-            m = re.match(r"(CSG=\d COUNT=\d PROBE=\d SPLIT=\d) (.*)", line.strip())
+            m = re.match(r"(CSG=\d COUNT=\d PROBE=\d SPLIT=\d(?: HCTX=\d)?) (.*)", line.strip())
             if m:
                 out["kres"][m.group(1)] = {k.strip().rsplit(" ", 1)[0]: int(k.strip().rsplit(" ", 1)[1]) for k in m.group(2).split("|")}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)

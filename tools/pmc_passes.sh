@@ -7,7 +7,7 @@ tag=$1; wl=${2:-S4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_${tag}_${name} -o $wl -- python3 bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 1 --workload $wl > gpurun_out/pmc_${tag}_${name}.log 2>&1
+  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_${tag}_${name} -o $wl -- python3 bench.py --no-cpu-baseline --no-secondary --steps 6 --warmup 2 --kernel-only --workload $wl > gpurun_out/pmc_${tag}_${name}.log 2>&1
 }
 # (GRBM_GUI_ACTIVE rides in the SAME pass as the counters it is divided into: kernel times differ by 10 % from pass to pass)
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
