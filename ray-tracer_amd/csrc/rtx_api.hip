@@ -24,7 +24,8 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
                                              uint8_t* rgb, int32_t* hit, unsigned long long* counters,
                                              int count_events, hipStream_t stream);
 extern "C" hipError_t rtx_launch_reset_counters(unsigned long long* counters, const int32_t* tile_cost, hipStream_t stream);
-extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, hipStream_t stream);
+extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, unsigned long long* time_sum,
+                                                hipStream_t stream);
 
 __global__ void debug_math_kernel(int op, long long n, const double* a, const double* b, double* out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +124,7 @@ void cull_sphere(const double* inverse16, const double* lc, double lr, float* ou
 
 // compile-time view of one op (head + body); split into the two device arrays at upload
 struct OpRec {
-    int32_t kind, level, skip, flags, shape, clevel, xf;
+    int32_t kind, level, skip, flags, shape, clevel, xf, regray;
     float cull[4];       // bounding sphere from the node's own extent / its local bounds (what the reference's bounds test implies)
     float cull_t[4];     // the product's sphere: shapes = cull; containers: around the children themselves (geom_sphere), CSG: around
                          // where SURVIVING hits can lie (extent_sphere) when that is tighter
@@ -267,6 +268,26 @@ struct Compiler {
         if (std::isfinite(t4[3]) && (!std::isfinite(ops[begin].cull_t[3]) || t4[3] < ops[begin].cull_t[3])) std::memcpy(ops[begin].cull_t, t4, sizeof t4);
     }
 
+    // true if every container BELOW `node` has exactly the identity as its inverse transform (the class XF_IDENTITY of make())
+    bool containers_below_are_identity(int node, int depth = 0) {
+        if (node < 0 || node >= d->n_nodes || depth > 300) return false;
+        const int kind = d->node_kind[node];
+        if (kind != RTX_NODE_GROUP && kind != RTX_NODE_CSG) return true;
+        const int fc = d->node_first_child[node], nc = d->node_child_count[node];
+        if (nc < 0 || fc < 0 || fc + nc > d->n_children) return false;
+        for (int i = 0; i < nc; i++) {
+            const int ch = d->children[fc + i];
+            if (ch < 0 || ch >= d->n_nodes) return false;
+            const int ck = d->node_kind[ch];
+            if (ck == RTX_NODE_GROUP || ck == RTX_NODE_CSG) {
+                const double* m = d->node_inverse + (size_t)ch * 16;
+                for (int k = 0; k < 16; k++) if (!(m[k] == ((k % 5 == 0) ? 1.0 : 0.0))) return false;
+                if (!containers_below_are_identity(ch, depth + 1)) return false;
+            }
+        }
+        return true;
+    }
+
     // returns the number of list entries the subtree can produce (for the CSG capacity check)
     int emit(int node, int level, bool list, int clevel) {
         if (err != RTX_OK) return 0;
@@ -328,9 +349,12 @@ struct Compiler {
             const int f = OPF_LIST | (root ? OPF_ROOT : 0);
             const int b = (int)ops.size();
             OpRec ob = make(node, OPK_CSG_BEGIN, level, f, cl); ob.shape = cop;
+            // a CSG root whose inner containers all have the identity transform (operands without a transform of their own: the
+            // usual case) needs ONE local ray for its whole program: it stays in registers, no LDS slot (rtx_device.h: OPH_REGRAY)
+            ob.regray = (root && ob.xf != XF_IDENTITY && err == RTX_OK && containers_below_are_identity(node)) ? 1 : 0;
             ops.push_back(ob);
             stack.push_back(b);
-            const int xf = ob.xf;
+            const int xf = ob.regray ? XF_IDENTITY : ob.xf;      // (for the slot accounting only)
             org_depth += xf != XF_IDENTITY; dir_depth += xf == XF_GENERAL;
             max_org = std::max(max_org, org_depth); max_dir = std::max(max_dir, dir_depth);
             const int left_op = (int)ops.size();
@@ -492,6 +516,7 @@ int build_csg_program(const std::vector<OpRec>& ops, int begin, int end, std::ve
             for (int k = 0; k < 6; k++) ok = ok && (std::isinf(o.bounds[k]) || std::fabs(o.bounds[k]) <= 1e100);   // NaN fails both
             if (!ok) r[0] |= 1u << 24;
             r[0] |= (uint32_t)o.xf << 25;
+            if (o.regray) r[0] |= 1u << 27;
             r[1] = (uint32_t)off[o.skip - begin];
         }
         r[2] = o.kind <= OPK_CUBE ? (uint32_t)i : (uint32_t)o.shape;     // shapes: their op index; CSG ops: the operator
@@ -574,6 +599,7 @@ int rtx_init(int device, rtx_ctx** out) {
     c->opt.probe_ahead = env_int("RTX_PROBE_AHEAD", -1);
     c->opt.hctx = env_int("RTX_HCTX", -1);
     c->opt.cost_feedback = env_int("RTX_COST_FEEDBACK", -1);
+    c->opt.time_lpt = env_int("RTX_TIME_LPT", -1);
     rtx_ctx::Lane& l0 = c->lanes[0];
     void* sticky_dev = nullptr;
     void* scratch_dev = nullptr;
@@ -658,6 +684,7 @@ int rtx_set_option(rtx_ctx* c, const char* name, int value) {
     else if (n == "probe_ahead") c->opt.probe_ahead = value;
     else if (n == "hctx") c->opt.hctx = value;
     else if (n == "cost_feedback") c->opt.cost_feedback = value;
+    else if (n == "time_lpt") c->opt.time_lpt = value;
     else return fail(c, RTX_E_INVALID, "unknown option '" + n + "'");
     return RTX_OK;
 }
@@ -929,7 +956,15 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
     // then varies by two orders of magnitude) and the dispatch is long; RTX_LPT=0/1 overrides.
     {
         const int n_tiles = rp.tiles_x * rp.n_bands_local;
-        const bool want = !(flags & RTX_F_INTERNAL_NO_LPT) && (ctx->opt.lpt >= 0 ? ctx->opt.lpt != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching));
+        // UNIFORM scenes (no material branches: a pixel traces 1-3 rays) have no use for a ray-count probe, but their tiles differ
+        // in how much TRAVERSAL a ray costs (a tile over a dense cluster takes several times the median) and the launch ends in a
+        // thinning tail of such waves.  With the tile-cost feedback they get a tile order too, from the second frame of a view on:
+        // every wave leaves its DURATION as the tile's cost (time mode), the next frame files the tiles by cost / mean.  Measured
+        // (tools/ms.py, same box): S3 4K 2.05 -> 1.98 ms, S5 8K 10.44 -> 9.97 ms; the three small launches it costs (zero, sum,
+        // classify: ~15 us) outweigh the gain on short dispatches (S2 1080p 0.36 -> 0.38 ms), hence the tile threshold.
+        const bool time_lpt = !(flags & RTX_F_INTERNAL_NO_LPT) && ctx->opt.lpt < 0 && ctx->opt.cost_feedback != 0 && ctx->opt.time_lpt != 0 && may_allocate &&
+                              !scene->dev.has_branching && n_tiles >= RTX_TIME_LPT_MIN_TILES;
+        const bool want = time_lpt || (!(flags & RTX_F_INTERNAL_NO_LPT) && (ctx->opt.lpt >= 0 ? ctx->opt.lpt != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching)));
         if (want && n_tiles > 0) {
             if (lane->tile_cap < (size_t)n_tiles) {
                 if (!may_allocate) return fail(ctx, RTX_E_CAPACITY, "frame has more tiles than the no-alloc scratch holds");
@@ -958,7 +993,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             // short dispatches are bounded by their longest wave (a glass pixel traces up to ~110 rays one after the
             // other), not by throughput: there the expensive tiles are rendered by 4 waves each, 4 lanes per pixel
             // sharing the pixel's ray tree (SPLIT kernels, rtx_kernel.hip).  RTX_SPLIT=0/1 and RTX_SPLIT_CLASS override.
-            const bool split = !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES) && lane->side &&
+            const bool split = !time_lpt && !(flags & RTX_F_INTERNAL_NO_SPLIT) && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : n_tiles <= RTX_SPLIT_MAX_TILES) && lane->side &&
                                scene->dev.has_csg != 2;      // (the general CSG kernels have no SPLIT variant)
             // PROBE AHEAD.  The probe is a chain of dependent rays on a few thousand waves: ~0.1 ms during which the chip is
             // nearly empty (2.5 % of a 4K frame).  When the caller's stream still holds work — frames are being queued one
@@ -988,7 +1023,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                     if (ce->cap < (size_t)n_tiles) {
                         if (ce->d_cost) (void)hipFree(ce->d_cost);         // (hipFree waits for the device: no launch still uses it)
                         ce->d_cost = nullptr; ce->cap = 0;
-                        HIPCHK(ctx, hipMalloc((void**)&ce->d_cost, (size_t)n_tiles * sizeof(int32_t)));
+                        HIPCHK(ctx, hipMalloc((void**)&ce->d_cost, ((size_t)n_tiles + 4) * sizeof(int32_t)));      // (+ the time mode's 8-byte sum)
                         ce->cap = n_tiles;
                     }
                     ce->hsize = cam->hsize; ce->vsize = cam->vsize; ce->band_first = bands.first; ce->band_stride = bands.stride; ce->max_depth = max_depth;
@@ -1003,6 +1038,10 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 ce->valid = true;
                 rp.tile_cost = ce->d_cost;
             }
+            if (time_lpt && !reuse) {
+                // first frame of a uniform scene's view: nothing to order by yet — plain permuted order, the waves measure
+                rp.tile_cost = (int32_t*)((uintptr_t)ce->d_cost | 1u);
+            } else {
             bool ahead = !split && !reuse && !(flags & (RTX_F_INTERNAL_NO_SPLIT | RTX_F_INTERNAL_NO_AHEAD)) && may_allocate && lane->side && ctx->opt.probe_ahead != 0;
             if (ahead && ctx->opt.probe_ahead < 0) ahead = hipStreamQuery(st) == hipErrorNotReady;
             (void)hipGetLastError();
@@ -1042,7 +1081,9 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             if (pp.max_depth < 0) pp.max_depth = 0;
             if (pp.max_depth > max_depth) pp.max_depth = max_depth; pp.tile_lists = lists; pp.tile_counts = counts;
             if (reuse) {
-                HIPCHK(ctx, rtx_launch_classify_tiles(ce->d_cost, n_tiles, lists, counts, pst));
+                unsigned long long* tsum = time_lpt ? (unsigned long long*)(ce->d_cost + ((ce->cap + 1) & ~(size_t)1)) : nullptr;
+                HIPCHK(ctx, rtx_launch_classify_tiles(ce->d_cost, n_tiles, lists, counts, tsum, pst));
+                if (time_lpt) rp.tile_cost = (int32_t*)((uintptr_t)ce->d_cost | 1u);
                 ctx->n_classify_launches++;
             } else {
                 HIPCHK(ctx, rtx_launch_trace_shade(&scene->dev, &cd, &pp, (uint8_t*)d_rgb, nullptr, d_counters, 0, pst));
@@ -1064,6 +1105,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 rp.split_guard = (int32_t)(g > 0x3fffffff ? 0x3fffffff : g);
                 if (ctx->opt.debug == 2) rp.split_guard = 1;        // test hook: every split wave gives up (sticky-error test)
             }
+            }   // (!time_lpt || reuse)
 #ifdef RTX_EXP_ORDER
             }
 #endif

@@ -45,6 +45,9 @@ struct __attribute__((aligned(32))) OpHead {   // 32 bytes = one s_load_dwordx8
 #define OPH_CLEVEL(i) ((int)(((i) >> 16) & 255u))
 #define OPH_NOFILTER(i) ((int)(((i) >> 24) & 1u))
 #define OPH_XF(i) ((int)(((i) >> 25) & 3u))         // containers: XF_* class of the inverse transform
+#define OPH_REGRAY(i) ((int)(((i) >> 27) & 1u))     // CSG root BEGIN: every container below it has the identity as its transform, so the
+                                                    //   root's local ray is the only one its program ever needs: it stays in registers
+                                                    //   and gets no LDS slot (rtx_kernel.hip: interpret)
 // class of a container's inverse transform (decided on the host from its exact bits): what entering it does to a ray
 enum { XF_GENERAL = 0,     // any affine map: origin and direction change
        XF_TRANSLATE = 1,   // linear part exactly the identity, w33 == 1: the direction is unchanged, origin = p + t
@@ -221,6 +224,7 @@ struct RenderParams {
 // cost classes of the tile-order lists: class k holds the tiles whose busiest pixel traces [RTX_CLASS_LO(k), RTX_CLASS_LO(k+1)) rays
 #define RTX_CLASS_OF_COST(c) ((c) < 4 ? 0 : (c) < 8 ? 1 : (c) < 16 ? 2 : (c) < 32 ? 3 : (c) < 48 ? 4 : (c) < 64 ? 5 : (c) < 96 ? 6 : 7)
 #define RTX_COST_OF_CLASS(k) ((k) == 0 ? 2 : (k) == 1 ? 6 : (k) == 2 ? 12 : (k) == 3 ? 24 : (k) == 4 ? 40 : (k) == 5 ? 56 : (k) == 6 ? 80 : 120)
+#define RTX_TIME_LPT_MIN_TILES 60000  /* uniform scenes: launches of at least this many tiles are ordered by measured wave durations */
 #define RTX_CNT_SLOTS 256
 #define RTX_GUARD_UNIT (1ull << 32)   /* the overflow counter's high half counts waves that tripped the SPLIT guard */
 #define RTX_CNT_STRIDE 32

@@ -253,6 +253,27 @@ DI unsigned cull_hit4(F16 p, float fox, float foy, float foz, float fdx, float f
     return cull_hit2(lo, fox, foy, foz, fdx, fdy, fdz, fdd, behind) | (cull_hit2(hi, fox, foy, foz, fdx, fdy, fdz, fdd, behind) << 2);
 }
 
+// Tile-cost feedback, the end of a frame wave (rtx_api.hip: enqueue_render): leaves the tile's cost for the next frame's tile
+// order — the traced rays of the tile's busiest pixel, or (uniform scenes: low bit of the word set) how long the wave ran, in
+// 10 ns ticks; the first word of the wave's LDS kept the start time.  The array's address waits in a spare word of the counter block.  Out of
+// line on purpose: inlined, the few registers it needs shift the allocation of the whole kernel (measured +1 to +2 % on the CSG
+// workload although it runs once per wave).
+__device__ __attribute__((noinline)) void tile_cost_tail(const unsigned long long* counters_base, int traced, unsigned t_start, int tile_index) {
+    const unsigned long long word = __hip_atomic_load(&counters_base[RTX_CNT_COST_PTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!word) return;
+    int32_t* const tile_cost = (int32_t*)(word & ~1ull);
+    int c;
+    if (word & 1ull) {
+        c = (int)((unsigned)__builtin_amdgcn_s_memrealtime() - (unsigned)__builtin_amdgcn_readfirstlane((int)t_start));
+        c = c < 1 ? 1 : c;
+    } else {
+        c = traced;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(c, o, 64); c = w > c ? w : c; }
+    }
+    if (threadIdx.x == 0) tile_cost[tile_index] = c;
+}
+
 enum { MODE_DONE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
 const uint32_t LBIT = 0x80000000u;
 
@@ -315,12 +336,16 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
     // if the transform has a linear part (rtx_device.h: XF_*): a pure translation leaves the direction as it is and the identity
     // leaves the whole ray, so those levels share their parent's slots (nested translated groups: 1.5 KB per level, not 3 KB).
     // slotmap: lane L holds (origin slot | direction slot << 8) of list level L (a VGPR used as a wave-uniform array)
-    extern __shared__ double lds_rays[];
+    // (the first 8 bytes of the wave's LDS keep its start time for the tile-cost feedback: a fixed address, so neither the store
+    // here nor the load at the end keeps a register live through the kernel)
+    extern __shared__ double lds_all[];
+    double* const lds_rays = lds_all + 1;
     double* const org_base = lds_rays + threadIdx.x;
     double* const dir_base = lds_rays + sc.n_org_slots * LDS_HALF_DOUBLES + threadIdx.x;
     double* const lds_after = lds_rays + (sc.n_org_slots + sc.n_dir_slots) * LDS_HALF_DOUBLES;
     int slotmap = 0;
     const int lane = threadIdx.x;
+    if (!PROBE && !SPLIT && lane == 0) *(volatile unsigned*)lds_all = (unsigned)__builtin_amdgcn_s_memrealtime();
     int tile = (int)(((unsigned long long)blockIdx.x * (unsigned)rp.tile_mul) % (unsigned)(rp.tiles_x * rp.n_bands_local));
 #ifdef RTX_NO_LOCKSTEP
     constexpr bool LOCKSTEP = false;                // (A/B builds: tools/lights_probe.py)
@@ -625,8 +650,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         V3 po, pd;
         float fox, foy, foz, fdx, fdy, fdz, fdd;
         int cached_level = -1;
+        bool reg_ray = false;             // inside a CSG root whose local ray lives in registers only (OPH_REGRAY): po / pd are it, at every level
         auto sync_level = [&](int level) {
             if (level == cached_level) return;
+            if (reg_ray) { cached_level = level; return; }
             const int sm = __builtin_amdgcn_readlane(slotmap, level);
             const double* so = org_base + (sm & 0xff) * LDS_HALF_DOUBLES;
             const double* sd = dir_base + (sm >> 8) * LDS_HALF_DOUBLES;
@@ -791,7 +818,16 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     } else {
                         // the children (level + 1) walk in this node's space
                         po = lo; pd = ld;
-                        enter_level(level, xf, pass);
+                        if (OPH_REGRAY(info)) {
+                            // every container below has the identity transform: this ray serves the whole program from registers
+                            const int sm = __builtin_amdgcn_readlane(slotmap, level);
+                            if (lane == level + 1) slotmap = sm;
+                            fox = (float)po.x; foy = (float)po.y; foz = (float)po.z;
+                            fdx = (float)pd.x; fdy = (float)pd.y; fdz = (float)pd.z;
+                            fdd = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+                            cached_level = level + 1;
+                            reg_ray = true;
+                        } else enter_level(level, xf, pass);
                         if (pass) set_start(OPH_CLEVEL(info), cnt);
                     }
                 }
@@ -950,6 +986,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
             TMI(tm_shade);
             cur = next;
         }
+        if (reg_ray) { reg_ray = false; cached_level = -1; }      // (the list walk re-reads its level's ray from LDS)
         };
 
         // ================= list-by-list traversal (everything outside CSG)
@@ -1705,17 +1742,10 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
 #endif
     // ---- tile-cost feedback: the traced rays of the tile's busiest pixel, for the next frame's tile order (split tiles keep
     // their last figure: their pixels' rays are spread over helper lanes).  The array's address waits in a spare counter word.
-    int32_t* tile_cost = nullptr;
-    if (!SPLIT) tile_cost = (int32_t*)__hip_atomic_load(&counters_base[RTX_CNT_COST_PTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (requested here, used below)
     // ---- ray / event counters: one atomic per wave per counter
     unsigned t0 = wave_sum(n_radiance), t1 = wave_sum(n_shadow), t2 = wave_sum(overflow), t3 = wave_sum(n_skipped);
     counters += (blockIdx.x % RTX_CNT_SLOTS) * RTX_CNT_STRIDE;      // this wave's replica (rtx_device.h)
-    if (!SPLIT && tile_cost) {
-        int c = (int)(n_radiance + n_shadow - n_skipped);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(c, o, 64); c = w > c ? w : c; }
-        if (lane == 0) tile_cost[bl * rp.tiles_x + tx] = c;        // (= the launch's tile index, rebuilt from what is live anyway)
-    }
+    if (!SPLIT) tile_cost_tail(counters_base, (int)(n_radiance + n_shadow - n_skipped), *(volatile unsigned*)lds_all, bl * rp.tiles_x + tx);
     if (lane == 0) {
         atomicAdd(&counters[RTX_CNT_RADIANCE], (unsigned long long)t0);
         atomicAdd(&counters[RTX_CNT_SHADOW], (unsigned long long)t1);
@@ -1747,7 +1777,7 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
     if (blocks <= 0) return hipSuccess;
     const bool split = !rp->probe && rp->use_lists && rp->split_cap > 0 && rp->split_launch;
     if (split) blocks = rp->split_cap << RTX_SPLIT_BITS;
-    size_t lds = (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_lds_entries * 64 * 12 + 15) & ~(size_t)15) +
+    size_t lds = 8 + (size_t)(sc->n_org_slots + sc->n_dir_slots) * LDS_HALF_DOUBLES * sizeof(double) + (((size_t)sc->csg_lds_entries * 64 * 12 + 15) & ~(size_t)15) +
                  (size_t)sc->csg_prog_lds * sizeof(uint32_t);
     if (split) lds += 64 * (3 * sizeof(double) + 2 * sizeof(int));
     // hit context in LDS (template flag HCTX): only if the wave's LDS still fits the occupancy the kernel is built for
@@ -1782,7 +1812,21 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
 // Files every tile of the launch under the class of its cost (rtx_device.h: RTX_CLASS_OF_COST) — what the probe launch does
 // from its own estimate, here from the costs the previous frame of the same view measured.  One thread per tile, one
 // wave-aggregated append per wave and class.
-__global__ __launch_bounds__(1024) void classify_tiles_kernel(const int32_t* __restrict__ cost, int n_tiles, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+// time mode (uniform scenes: the cost is the wave's duration): classes by the ratio to the launch's MEAN cost, which
+// cost_sum_kernel leaves in *sum first
+__global__ __launch_bounds__(1024) void cost_sum_kernel(const int32_t* __restrict__ cost, int n_tiles, unsigned long long* __restrict__ sum) {
+    __shared__ unsigned long long part[16];
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    unsigned long long v = t < n_tiles ? (unsigned long long)(unsigned)cost[t] : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long a = 0; for (int i = 0; i < 16; i++) a += part[i]; atomicAdd(sum, a); }
+}
+
+__global__ __launch_bounds__(1024) void classify_tiles_kernel(const int32_t* __restrict__ cost, int n_tiles, int32_t* __restrict__ lists, int32_t* __restrict__ counts,
+                                                              const unsigned long long* __restrict__ sum) {
     // (all waves of a launch appending to the same eight counters serialise at ~12 ns per atomic — 60 us for a 4K frame; a block
     // of 1024 tiles first counts in LDS, then reserves its ranges with ONE global atomic per class)
     __shared__ int cnt[RTX_TILE_CLASSES], base[RTX_TILE_CLASSES];
@@ -1790,7 +1834,15 @@ __global__ __launch_bounds__(1024) void classify_tiles_kernel(const int32_t* __r
     const int lane = (int)(threadIdx.x & 63);
     if (threadIdx.x < RTX_TILE_CLASSES) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int cls = t < n_tiles ? RTX_CLASS_OF_COST(cost[t]) : -1;
+    int cls = -1;
+    if (t < n_tiles) {
+        if (sum) {
+            // 16 x cost / mean -> class: < 0.6, < 0.85, < 1.1, < 1.4, < 1.8, < 2.4, < 3.5, more
+            const unsigned long long mean16 = (*sum + (unsigned long long)n_tiles - 1) / (unsigned long long)n_tiles;
+            const unsigned long long r = mean16 ? ((unsigned long long)(unsigned)cost[t] * 160ull) / mean16 : 0ull;     // 10 x ratio x 16
+            cls = r < 96 ? 0 : r < 136 ? 1 : r < 176 ? 2 : r < 224 ? 3 : r < 288 ? 4 : r < 384 ? 5 : r < 560 ? 6 : 7;
+        } else cls = RTX_CLASS_OF_COST(cost[t]);
+    }
     int off = 0;                                   // this tile's position among the block's tiles of its class
     for (int k = 0; k < RTX_TILE_CLASSES; k++) {
         const unsigned long long m = __ballot(cls == k);
@@ -1807,10 +1859,17 @@ __global__ __launch_bounds__(1024) void classify_tiles_kernel(const int32_t* __r
     if (cls >= 0) lists[(size_t)cls * n_tiles + base[cls] + off] = t;
 }
 
-extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, hipStream_t stream) {
+extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles, int32_t* lists, int32_t* counts, unsigned long long* time_sum,
+                                                hipStream_t stream) {
     static_assert(RTX_TILE_CLASSES == 8, "RTX_CLASS_OF_COST files into 8 classes");
     if (n_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(classify_tiles_kernel, dim3((unsigned)((n_tiles + 1023) / 1024)), dim3(1024), 0, stream, cost, n_tiles, lists, counts);
+    const dim3 grid((unsigned)((n_tiles + 1023) / 1024)), block(1024);
+    if (time_sum) {
+        hipError_t e = hipMemsetAsync(time_sum, 0, sizeof(unsigned long long), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(cost_sum_kernel, grid, block, 0, stream, cost, n_tiles, time_sum);
+    }
+    hipLaunchKernelGGL(classify_tiles_kernel, grid, block, 0, stream, cost, n_tiles, lists, counts, (const unsigned long long*)time_sum);
     return hipGetLastError();
 }
 
