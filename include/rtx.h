@@ -172,9 +172,9 @@ int  rtx_ctx_poll(rtx_ctx*, int wait);
 
 /* Scheduling knobs of a context (they never change an image).  Defaults come from the environment
  * ONCE, at rtx_init (RTX_LPT, RTX_TILE_MUL, RTX_PROBE_DEPTH, RTX_SPLIT, RTX_SPLIT_CLASS, RTX_PROBE_AHEAD, RTX_STREAM_LPT,
- * RTX_HOST_SETS, RTX_PIPELINE, RTX_HCTX, RTX_COST_FEEDBACK); names here: "lpt", "tile_mul", "probe_depth", "split", "split_class",
- * "probe_ahead", "stream_lpt", "host_sets", "pipeline", "hctx", "cost_feedback"; value -1 = the default for "lpt", "split",
- * "probe_ahead", "stream_lpt", "hctx" and "cost_feedback".
+ * RTX_HOST_SETS, RTX_PIPELINE, RTX_HCTX, RTX_COST_FEEDBACK, RTX_TIME_LPT); names here: "lpt", "tile_mul", "probe_depth", "split", "split_class",
+ * "probe_ahead", "stream_lpt", "host_sets", "pipeline", "hctx", "cost_feedback", "time_lpt"; value -1 = the default for "lpt",
+ * "split", "probe_ahead", "stream_lpt", "hctx", "cost_feedback" and "time_lpt".
  * No counterpart in the reference (it has no scheduler). */
 int  rtx_set_option(rtx_ctx*, const char* name, int value);
 /* Diagnostic, no counterpart in the reference: launches of the scheduler so far — "probe_launches" (tile-order probes) and

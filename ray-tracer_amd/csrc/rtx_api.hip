@@ -963,7 +963,7 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
         // (tools/ms.py, same box): S3 4K 2.05 -> 1.98 ms, S5 8K 10.44 -> 9.97 ms; the three small launches it costs (zero, sum,
         // classify: ~15 us) outweigh the gain on short dispatches (S2 1080p 0.36 -> 0.38 ms), hence the tile threshold.
         const bool time_lpt = !(flags & RTX_F_INTERNAL_NO_LPT) && ctx->opt.lpt < 0 && ctx->opt.cost_feedback != 0 && ctx->opt.time_lpt != 0 && may_allocate &&
-                              !scene->dev.has_branching && n_tiles >= RTX_TIME_LPT_MIN_TILES;
+                              !scene->dev.has_branching && n_tiles >= (ctx->opt.time_lpt > 0 ? ctx->opt.time_lpt : RTX_TIME_LPT_MIN_TILES);
         const bool want = time_lpt || (!(flags & RTX_F_INTERNAL_NO_LPT) && (ctx->opt.lpt >= 0 ? ctx->opt.lpt != 0 : (max_depth >= 1 && n_tiles >= 2048 && scene->dev.has_branching)));
         if (want && n_tiles > 0) {
             if (lane->tile_cap < (size_t)n_tiles) {

@@ -24,7 +24,8 @@ struct rtx_opts {
     int host_sets = 0;       // rtx_render (host buffers): band sets a whole frame is rendered and copied out in; 0 = by size, 1 = one launch
     int cost_feedback = -1;  // tile order from the costs the previous frame of the same view measured, instead of a probe launch:
                              // -1 / 1 = on, 0 = off (always probe)
-    int time_lpt = -1;       // uniform scenes (no branching material): tile order from the wave durations the previous frame measured; 0 = off
+    int time_lpt = -1;       // uniform scenes (no branching material): tile order from the wave durations the previous frame measured: -1 = launches of at least
+                             // RTX_TIME_LPT_MIN_TILES tiles, 0 = off, n > 0 = launches of at least n tiles
     int hctx = -1;           // hit context in LDS instead of registers: -1 = where the wave's LDS budget allows (rtx_kernel.hip), 0 / 1 = forced
     int pipeline = 3;        // rtx_render_gathered: frames in flight, each on a render lane of its own (read at rtx_comm_init_*;
                              // 2..4; below 2 = every frame on the caller's stream)

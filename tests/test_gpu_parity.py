@@ -842,6 +842,41 @@ def test_tile_cost_feedback_orders_tiles_without_changing_the_image(ctx):
 
 
 
+@pytest.mark.parametrize("name,w,h", [("S3", 333, 171), ("S5", 320, 200), ("S2", 200, 120)])
+def test_time_ordered_tiles_of_uniform_scenes_do_not_change_the_image(ctx, name, w, h):
+    """Uniform scenes (no branching material) get their tile order from the wave DURATIONS the previous frame of the view measured
+    (time mode of the tile-cost feedback; by default only for launches of >= RTX_TIME_LPT_MIN_TILES tiles, forced here for
+    small frames with option time_lpt = 1).  Scheduling only: frames 2.. of a view (ordered) must equal frame 1 (plain
+    permuted order) and the renders with the feature off, ids and counts included; band sets too."""
+    import rtx
+    pw, pc = rtx.load_yaml(parity.scene_text(name, w, h))
+    sc = ctx.scene(pw)
+    try:
+        ctx.set_option("time_lpt", 0)
+        want = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
+        want_b = [sc.render(pc[0], 5, bands=(g, 2), flags=rtx.F_BANDS_COMPACT) for g in range(2)]
+        ctx.set_option("time_lpt", 1)
+        c0 = rtx.LIB.rtx_debug_counter(ctx.h, b"classify_launches")
+        p0 = rtx.LIB.rtx_debug_counter(ctx.h, b"probe_launches")
+        for k in range(4):
+            got = sc.render(pc[0], 5, flags=rtx.F_COUNT_EVENTS)
+            assert np.array_equal(got["rgb"], want["rgb"]) and np.array_equal(got["hit"], want["hit"]), (name, k)
+            assert got["stats"].rays == want["stats"].rays
+            ge, we = got["stats"].events(), want["stats"].events()
+            assert {k2: ge[k2] for k2 in ge if k2 not in ("lane_slots", "op_slots")} == {k2: we[k2] for k2 in we if k2 not in ("lane_slots", "op_slots")}, (name, k)
+        for rep in range(2):
+            for g in range(2):
+                got = sc.render(pc[0], 5, bands=(g, 2), flags=rtx.F_BANDS_COMPACT)
+                assert np.array_equal(got["rgb"], want_b[g]["rgb"]) and np.array_equal(got["hit"], want_b[g]["hit"]), (name, g)
+        # the first frame of each of the three views only measures; the others are ordered by a classify launch; never a probe
+        assert rtx.LIB.rtx_debug_counter(ctx.h, b"classify_launches") - c0 == 3 + 2
+        assert rtx.LIB.rtx_debug_counter(ctx.h, b"probe_launches") == p0
+    finally:
+        ctx.set_option("time_lpt", -1)
+        sc.close()
+
+
+
 def test_host_render_in_band_sets_equals_one_launch(ctx):
     """rtx_render of a whole frame into host buffers renders large frames as 2..8 interleaved band sets on two lanes and copies
     each set out while the next ones render (option host_sets; 0 = by frame size).  Forced here on small ragged frames:
