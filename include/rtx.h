@@ -230,7 +230,11 @@ int  rtx_comm_size(const rtx_comm*);
  * machine's hardware queues when it was created (wanted: frames in flight + 1; 1 = everything serialises). */
 int  rtx_comm_concurrency(const rtx_comm*);
 
-/* Camera::render (camera.rs:39-54) on all ranks of `comm`: queues this rank's bands, then the all-gather and the
+/* COLLECTIVE: every rank of `comm` must make the same sequence of rtx_render_gathered calls.  Once a rank's buffers exist the
+ * all-gather is queued whatever happens to that rank's own render (an earlier frame's overflow, a failed launch), and the
+ * rank-local error is returned AFTER it, so the other ranks never wait for a rank that gave up; only invalid arguments (the
+ * same on every rank) or an allocation failure return without the collective.
+ * Camera::render (camera.rs:39-54) on all ranks of `comm`: queues this rank's bands, then the all-gather and the
  * de-interleave on the communicator's own stream.  Consecutive calls render on alternating internal render lanes (three
  * frames in flight by default; option "pipeline" / RTX_PIPELINE = 1..4, read when the communicator is created), each
  * behind the work `stream` (NULL = the context's) holds at the time of the call: the start of frame k+1 fills the wave
@@ -248,7 +252,10 @@ int  rtx_comm_wait(rtx_comm*, void* stream);
 /* The same frame from ONE host thread that owns all N GPUs: comms[i] / scenes[i] belong to rank i (rtx_comm_init_all;
  * the same scene description uploaded to every context).  Renders, gathers (one grouped all-gather), assembles on rank
  * 0's GPU and copies to host buffers (rgb: hsize*vsize*3, hit: NULL or hsize*vsize int32).  stats: NULL or the whole
- * frame's counts (sum over ranks).  With n == 1 the same calls run with a one-rank communicator. */
+ * frame's counts (sum over ranks).  NOTE: with stats != NULL every rank's render is waited for before the next rank's is
+ * queued (each rank's counters are read back synchronously), so the ranks render ONE AFTER THE OTHER and stats->kernel_ms is
+ * the slowest rank's own time, not a concurrent measurement; pass NULL when timing the frame.  With n == 1 the same calls
+ * run with a one-rank communicator. */
 int  rtx_render_multi(rtx_comm* const* comms, const rtx_scene* const* scenes, int n, const rtx_camera*, int max_depth,
                       uint32_t flags, uint8_t* rgb, int32_t* hit, rtx_stats* stats);
 
