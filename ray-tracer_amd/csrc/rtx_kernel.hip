@@ -1814,21 +1814,23 @@ extern "C" hipError_t rtx_launch_trace_shade(const SceneDev* sc, const CameraDev
 // wave-aggregated append per wave and class.
 // time mode (uniform scenes: the cost is the wave's duration): classes by the ratio to the launch's MEAN cost, which
 // cost_sum_kernel leaves in *sum first
-__global__ __launch_bounds__(1024) void cost_sum_kernel(const int32_t* __restrict__ cost, int n_tiles, unsigned long long* __restrict__ sum) {
-    __shared__ unsigned long long part[16];
+__global__ __launch_bounds__(256) void cost_sum_kernel(const int32_t* __restrict__ cost, int n_tiles, unsigned long long* __restrict__ sum) {
+    __shared__ unsigned long long part[4];
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     unsigned long long v = t < n_tiles ? (unsigned long long)(unsigned)cost[t] : 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { unsigned long long a = 0; for (int i = 0; i < 16; i++) a += part[i]; atomicAdd(sum, a); }
+    if (threadIdx.x == 0) { unsigned long long a = 0; for (int i = 0; i < 4; i++) a += part[i]; atomicAdd(sum, a); }
 }
 
-__global__ __launch_bounds__(1024) void classify_tiles_kernel(const int32_t* __restrict__ cost, int n_tiles, int32_t* __restrict__ lists, int32_t* __restrict__ counts,
+__global__ __launch_bounds__(256) void classify_tiles_kernel(const int32_t* __restrict__ cost, int n_tiles, int32_t* __restrict__ lists, int32_t* __restrict__ counts,
                                                               const unsigned long long* __restrict__ sum) {
     // (all waves of a launch appending to the same eight counters serialise at ~12 ns per atomic — 60 us for a 4K frame; a block
-    // of 1024 tiles first counts in LDS, then reserves its ranges with ONE global atomic per class)
+    // of 256 tiles first counts in LDS, then reserves its ranges with ONE global atomic per class.  Blocks of four waves on
+    // purpose: the launch runs beside frame launches that keep every wave slot busy, and a 1024-thread block would have to wait
+    // until ONE compute unit has sixteen free slots at the same moment — measured 0.8 ms on average in a streamed run)
     __shared__ int cnt[RTX_TILE_CLASSES], base[RTX_TILE_CLASSES];
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int lane = (int)(threadIdx.x & 63);
@@ -1863,7 +1865,7 @@ extern "C" hipError_t rtx_launch_classify_tiles(const int32_t* cost, int n_tiles
                                                 hipStream_t stream) {
     static_assert(RTX_TILE_CLASSES == 8, "RTX_CLASS_OF_COST files into 8 classes");
     if (n_tiles <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n_tiles + 1023) / 1024)), block(1024);
+    const dim3 grid((unsigned)((n_tiles + 255) / 256)), block(256);
     if (time_sum) {
         hipError_t e = hipMemsetAsync(time_sum, 0, sizeof(unsigned long long), stream);
         if (e != hipSuccess) return e;
