@@ -6,7 +6,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +60,58 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
 static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];
 
 int rtx_earlier_overflow(rtx_ctx* ctx);
+
+// The host's share of rtx_render's band-set pipeline: a landed set's bands go from pinned staging to their rows of the caller's
+// (pageable) image.  One thread moves ~10 GB/s, which made the host the bottleneck of an 8K frame (99.5 MB) and left the last
+// set's copy exposed on every frame; a few persistent workers share the copies of a set (the caller's thread takes part).
+struct rtx_copy_pool {
+    struct Job { const uint8_t* src; uint8_t* dst; size_t n; };
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::vector<Job>* jobs = nullptr;
+    std::atomic<size_t> next{0};
+    size_t acks = 0;                         // workers that have finished with the current generation's job list
+    unsigned long long generation = 0;
+    bool stop = false;
+
+    explicit rtx_copy_pool(int n) {
+        for (int i = 0; i < n; i++) workers.emplace_back([this] { loop(); });
+    }
+    ~rtx_copy_pool() {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        wake.notify_all();
+        for (std::thread& t : workers) t.join();
+    }
+    void drain(const std::vector<Job>& js) {
+        for (size_t i; (i = next.fetch_add(1)) < js.size();) std::memcpy(js[i].dst, js[i].src, js[i].n);
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::vector<Job>* js;
+            {
+                std::unique_lock<std::mutex> g(m);
+                wake.wait(g, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation; js = jobs;
+            }
+            drain(*js);
+            { std::lock_guard<std::mutex> g(m); acks++; }
+            done.notify_one();
+        }
+    }
+    // copies every job (they must not overlap); returns when all are done AND every worker has let go of the list
+    void run(const std::vector<Job>& js) {
+        if (js.empty()) return;
+        { std::lock_guard<std::mutex> g(m); jobs = &js; next = 0; acks = 0; generation++; }
+        wake.notify_all();
+        drain(js);
+        std::unique_lock<std::mutex> g(m);
+        done.wait(g, [&] { return acks == workers.size(); });
+        jobs = nullptr;
+    }
+};
 
 namespace {
 
@@ -660,6 +716,10 @@ void rtx_shutdown(rtx_ctx* c) {
         if (c->lanes[l].ev_fork) (void)hipEventDestroy(c->lanes[l].ev_fork);
         if (c->lanes[l].ev_join) (void)hipEventDestroy(c->lanes[l].ev_join);
     }
+    delete c->copy_pool; c->copy_pool = nullptr;
+    for (hipEvent_t e : c->set_events) if (e) (void)hipEventDestroy(e);
+    c->set_events.clear();
+    if (c->h_batch_counters) (void)hipHostFree(c->h_batch_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_sticky) (void)hipHostFree((void*)c->h_sticky);
@@ -1249,13 +1309,25 @@ int render_chunked(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
             ln.tile_cap = set_tiles;
         }
     }
-    std::vector<hipEvent_t> ev((size_t)3 * C, nullptr);              // per set: begin, end (timed), landed in staging
-    auto drop_events = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
-    for (size_t i = 0; i < ev.size(); i++)
-        if ((i % 3 == 2 ? hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) : hipEventCreate(&ev[i])) != hipSuccess) {
-            drop_events(); return fail(ctx, RTX_E_DEVICE, "hipEventCreate failed");
-        }
+    // per set: begin, end (timed), landed in staging.  The events and the pinned copy of the counter blocks live with the
+    // context: creating 3 C events, destroying them and a synchronous counter copy were ~0.3 ms of every frame
+    std::vector<hipEvent_t>& ev = ctx->set_events;
+    while (ev.size() < (size_t)3 * C) {
+        hipEvent_t e = nullptr;
+        if ((ev.size() % 3 == 2 ? hipEventCreateWithFlags(&e, hipEventDisableTiming) : hipEventCreate(&e)) != hipSuccess)
+            return fail(ctx, RTX_E_DEVICE, "hipEventCreate failed");
+        ev.push_back(e);
+    }
+    auto drop_events = [&]() { };
+    if ((size_t)C > ctx->h_batch_cap) {
+        if (ctx->h_batch_counters) (void)hipHostFree(ctx->h_batch_counters);
+        ctx->h_batch_counters = nullptr; ctx->h_batch_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_batch_counters, (size_t)C * kCounterWords * sizeof(unsigned long long), hipHostMallocDefault));
+        ctx->h_batch_cap = C;
+    }
     uint8_t* const stage_hit = ctx->h_stage + C * chunk_px * 3;
+    if (!ctx->copy_pool) ctx->copy_pool = new rtx_copy_pool(env_int("RTX_COPY_THREADS", 4) - 1);     // (+ the caller's thread)
+    std::vector<rtx_copy_pool::Job> copy_jobs;
     for (int i = 0; i < C && rc == RTX_OK; i++) {
         rtx_ctx::Lane& ln = ctx->lanes[i & 1];
         rc = enqueue_render(ctx, scene, cam, max_depth, rtx_bands{i, C}, flags | RTX_F_BANDS_COMPACT | RTX_F_INTERNAL_NO_SPLIT,
@@ -1264,33 +1336,35 @@ int render_chunked(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
         if (rc != RTX_OK) break;
         if (hipMemcpyAsync(ctx->h_stage + (size_t)i * chunk_px * 3, ctx->d_rgb + (size_t)i * chunk_px * 3, chunk_px * 3, hipMemcpyDeviceToHost, ln.stream) != hipSuccess ||
             (hit && hipMemcpyAsync(stage_hit + (size_t)i * chunk_px * 4, ctx->d_hit + (size_t)i * chunk_px, chunk_px * 4, hipMemcpyDeviceToHost, ln.stream) != hipSuccess) ||
-            hipEventRecord(ev[3 * i + 2], ln.stream) != hipSuccess)
+            hipEventRecord(ev[3 * i + 2], ln.stream) != hipSuccess ||
+            hipMemcpyAsync(ctx->h_batch_counters + (size_t)i * kCounterWords, ctx->d_batch_counters + (size_t)i * kCounterWords,
+                           kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ln.stream) != hipSuccess)
             rc = fail(ctx, RTX_E_DEVICE, "device to host copy failed");
     }
     // the host's share: a set's bands go to their rows as soon as the set has landed
     for (int i = 0; i < C && rc == RTX_OK; i++) {
         if (hipEventSynchronize(ev[3 * i + 2]) != hipSuccess) { rc = fail(ctx, RTX_E_DEVICE, "hipEventSynchronize failed"); break; }
+        copy_jobs.clear();
         for (int k = 0; i + k * C < nb_total; k++) {
             const size_t y0 = (size_t)(i + k * C) * RTX_TILE;
             size_t rows = cam->vsize - y0; if (rows > RTX_TILE) rows = RTX_TILE;
             const size_t src_px = (size_t)i * chunk_px + (size_t)k * RTX_TILE * W;
-            std::memcpy(rgb + y0 * W * 3, ctx->h_stage + src_px * 3, rows * W * 3);
-            if (hit) std::memcpy(hit + y0 * W, stage_hit + src_px * 4, rows * W * 4);
+            copy_jobs.push_back({ctx->h_stage + src_px * 3, rgb + y0 * W * 3, rows * W * 3});
+            if (hit) copy_jobs.push_back({stage_hit + src_px * 4, (uint8_t*)(hit + y0 * W), rows * W * 4});
         }
+        ctx->copy_pool->run(copy_jobs);
     }
     // nothing of this call may still be running when it returns
     for (int l = 0; l < 2; l++)
         if (hipStreamSynchronize(ctx->lanes[l].stream) != hipSuccess && rc == RTX_OK) rc = fail(ctx, RTX_E_DEVICE, "hipStreamSynchronize failed");
     if (rc == RTX_OK) {
-        std::vector<unsigned long long> rep((size_t)C * kCounterWords);
-        if (hipMemcpy(rep.data(), ctx->d_batch_counters, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(ctx, RTX_E_DEVICE, "counter copy failed");
+        const unsigned long long* rep = ctx->h_batch_counters;           // (landed: both lanes were waited for above)
         rtx_stats sum; std::memset(&sum, 0, sizeof sum);
         for (int i = 0; i < C && rc == RTX_OK; i++) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev[0], ev[3 * i + 1]) != hipSuccess) { rc = fail(ctx, RTX_E_DEVICE, "hipEventElapsedTime failed"); break; }
             rtx_stats one;
-            rc = fill_stats(ctx, cam, rtx_bands{i, C}, rep.data() + (size_t)i * kCounterWords, ms, &one);
+            rc = fill_stats(ctx, cam, rtx_bands{i, C}, rep + (size_t)i * kCounterWords, ms, &one);
             sum.rays_primary += one.rays_primary; sum.rays_shadow += one.rays_shadow; sum.rays_secondary += one.rays_secondary;
             for (int k = 0; k < RTX_EV_COUNT; k++) sum.ev[k] += one.ev[k];
             sum.overflow_pixels += one.overflow_pixels; sum.rays_shadow_skipped += one.rays_shadow_skipped;

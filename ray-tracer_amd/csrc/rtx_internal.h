@@ -34,6 +34,7 @@ struct rtx_opts {
 constexpr size_t RTX_COUNTER_WORDS = (size_t)RTX_CNT_SLOTS * RTX_CNT_STRIDE;   // one replicated counter block
 
 struct rtx_scene;
+struct rtx_copy_pool;        // rtx_api.hip: a few host threads that move landed band sets from pinned staging into the caller's image
 
 struct rtx_ctx {
     int device = 0;
@@ -59,6 +60,9 @@ struct rtx_ctx {
     static constexpr int kLanes = 4;
     Lane lanes[kLanes];
     uint8_t* h_stage = nullptr; size_t stage_cap = 0;                        // pinned staging of a batch's images
+    rtx_copy_pool* copy_pool = nullptr;                                      // created by the first band-set render (rtx_render)
+    std::vector<hipEvent_t> set_events;                                      // band-set renders: 3 events per set, kept between calls
+    unsigned long long* h_batch_counters = nullptr; size_t h_batch_cap = 0;  // pinned copy of the sets' counter blocks
     uint8_t* d_rgb = nullptr; size_t rgb_cap = 0;
     int32_t* d_hit = nullptr; size_t hit_cap = 0;
     unsigned long long* d_batch_counters = nullptr; size_t batch_cap = 0;   // one counter block per frame of a batch
