@@ -1224,6 +1224,8 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                     if (CSG) rb = crp[1];
                     EV(RTX_EV_OP_SLOTS, 1);
                     const bool test = act && !own_miss();
+                    DV(16, 1);                                  // (diag build) slot 16: 64 x group visits; 18: 64 x visits that run the bounds filter
+                    if (__any(test)) DV(18, 1);
                     if (__any(test)) {
                         const int xf = CONT_XF(cflags);
                         V3 lo, ld;
@@ -1467,7 +1469,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
         }
         TMS(tm_ffwd);
 
-        DVW(16, lights_done); DV(17, lights_done ? 1 : 0);                            // children decision: waves x 64 / lanes
+        DV(17, lights_done ? 1 : 0);                                                  // children decision: lanes
         if (lights_done) {
             // ---- rest of shade_hit (world.rs:138-148): decide the children
             const MaterialRec* m = sc.materials + hmat;

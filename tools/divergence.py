@@ -32,5 +32,5 @@ for name in sys.argv[1:] or ["S4"]:
     print("  lighting block entered in %5.1f %% of iterations; lanes in it           %s" % (100.0 * e[10] / e[0], frac(e[11], e[10])))
     print("    pattern look-up (non-plain material)                     %s   (entered in %.1f %% of lighting blocks)" % (frac(e[13], e[12]), 100.0 * e[12] / max(e[10], 1)))
     print("    lit branch (diffuse + specular + pow)                    %s   (entered in %.1f %%)" % (frac(e[15], e[14]), 100.0 * e[14] / max(e[10], 1)))
-    print("  children decision block entered in %5.1f %% of iterations; lanes in it  %s" % (100.0 * e[16] / e[0], frac(e[17], e[16])))
+    print("  group visits per wave-iteration %.2f, of which run the transform + bounds filter %.2f" % (e[16] / 64.0 / iters, e[18] / 64.0 / iters))
     sc.close()
