@@ -20,8 +20,8 @@ the kernel's own event counters / the kernel's launch time measured with HIP eve
 stream; `valu_issue_frac`, `resident_waves` and `traffic` come from the rocprofv3 PMC passes recorded in
 profiles/<tag>_counters.json together with the git revision they were taken at), `cpu_baseline` (the
 CPU oracle — a C++ restatement of the single-threaded reference, `kind: "port"` — timed on a bounded
-tile sample of the same frame on this box's host cores, rank 0, N = 1 only) and `secondary` (the other
-3840x2160 configuration, S3, measured the same way in the same run).  At N = 1 the line also carries
+tile sample of the same frame on this box's host cores, rank 0, N = 1 only) and `secondary` / `secondary_c5` (the other
+3840x2160 configuration, S3, and the 7680x4320 CSG configuration, S5, measured the same way in the same run).  At N = 1 the line also carries
 `kernel_region` (the same K frames through rtx_render_device, one HIP event pair per launch on the
 launch stream: the average launch duration the roofline is priced with) and `host_render_ms`
 (rtx_render of the same frame into pageable host memory: what Camera::render, camera.rs:39-54, returns).
@@ -417,7 +417,17 @@ def main():
             out["secondary"] = {"config": {"workload": "S3: %s" % s3["desc"], "width": s3["width"], "height": s3["height"],
                                            "rays_per_frame": s3["rays_frame"], "rays": s3["rays"]},
                                 "value": s3["value"], "unit": "Mrays/s", "ms_per_step": s3["ms_per_step"], "steps": args.steps,
-                                "roofline": s3["roofline"]}
+                                "ms_per_frame_one_at_a_time": s3["one_ms"], "kernel_region": s3["kernel_region"],
+                                "host_render_ms": s3["host_ms"], "roofline": s3["roofline"]}
+    if N == 1 and not args.no_secondary and args.workload == "S4" and not args.width and not args.height and not args.kernel_only:
+        # C5 of BASELINE.json (the 8K CSG scene, defined as the 8-GPU configuration) on this one GPU, same way, fewer steps
+        s5 = measure("S5", 0, 0, max(4, args.steps // 2), 2)
+        if rank == 0:
+            out["secondary_c5"] = {"config": {"workload": "S5: %s" % s5["desc"], "width": s5["width"], "height": s5["height"],
+                                              "rays_per_frame": s5["rays_frame"], "rays": s5["rays"]},
+                                   "value": s5["value"], "unit": "Mrays/s", "ms_per_step": s5["ms_per_step"], "steps": max(4, args.steps // 2),
+                                   "ms_per_frame_one_at_a_time": s5["one_ms"], "kernel_region": s5["kernel_region"],
+                                   "host_render_ms": s5["host_ms"], "roofline": s5["roofline"]}
     if rank == 0:
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["text"], m["width"], m["height"])
