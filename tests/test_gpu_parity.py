@@ -581,6 +581,67 @@ class _Hip:
         return out
 
 
+def test_general_csg_scenes_through_every_entry_point(ctx):
+    """Scenes whose CSG roots exceed the fast kernels' bounds (general CSG kernels: lists in the device arena, one slot claimed per
+    wave) through every way of rendering: rtx_render (one launch and band sets on two lanes, i.e. two launches claiming slots at
+    the same time), tile lists and split tiles forced on (the general kernels have no SPLIT variant: the request is ignored),
+    rtx_render_device on a caller's stream, the no-alloc entry point (the arena is allocated with the scene), a batch of
+    cameras on four lanes, and the 3-rank band path of a loopback communicator.  All must equal the plain render."""
+    import ctypes as C
+    import fuzz_api
+    import rtx
+    hip = _Hip()
+    rng = np.random.default_rng(20261114)
+    bufs = []
+    try:
+        for i in range(3):
+            p = fuzz_api.plan(rng, 160, 96, big_csg=True)
+            pw, pc = fuzz_api.build(rtx.API, p)
+            sc = ctx.scene(pw)
+            try:
+                ctx.set_option("host_sets", 1)
+                want = sc.render(pc, 5)
+                assert (want["hit"] >= 0).any()
+                H, W = pc.vsize, pc.hsize
+                for sets in (2, 3):
+                    ctx.set_option("host_sets", sets)
+                    got = sc.render(pc, 5)
+                    assert np.array_equal(got["rgb"], want["rgb"]) and np.array_equal(got["hit"], want["hit"]), (i, sets)
+                ctx.set_option("host_sets", 1)
+                ctx.options(lpt=1, split=1, split_class=1)
+                got = sc.render(pc, 5)
+                assert np.array_equal(got["rgb"], want["rgb"]) and np.array_equal(got["hit"], want["hit"]) and got["stats"].rays == want["stats"].rays, i
+                ctx.options(lpt=-1, split=-1, split_class=7)
+                rgb = hip.malloc(H * W * 3, 0x11); ids = hip.malloc(H * W * 4, 0x22); rgb2 = hip.malloc(H * W * 3, 0x11)
+                bufs += [rgb, ids, rgb2]
+                st = sc.render_device(pc, rgb.value, ids.value, 5, stats=True)
+                assert st.rays == want["stats"].rays
+                sc.render_device_noalloc(pc, rgb2.value, 0, 5)
+                ctx.poll(wait=True)
+                for b in (rgb, rgb2):
+                    assert np.array_equal(hip.to_host(b, H * W * 3, np.uint8).reshape(H, W, 3), want["rgb"]), i
+                assert np.array_equal(hip.to_host(ids, H * W * 4, np.int32).reshape(H, W), want["hit"]), i
+                for one in sc.render_batch([pc] * 5, 5):
+                    assert np.array_equal(one["rgb"], want["rgb"]) and np.array_equal(one["hit"], want["hit"]), i
+                comm = rtx.Comm.loopback(ctx, 3)
+                try:
+                    frame = hip.malloc(H * W * 3, 0x33); bufs.append(frame)
+                    for rep in range(3):
+                        comm.render_gathered(sc, pc, frame.value, 0, 5)
+                    comm.wait()
+                    assert np.array_equal(hip.to_host(frame, H * W * 3, np.uint8).reshape(H, W, 3), want["rgb"]), i
+                finally:
+                    comm.close()
+            finally:
+                ctx.options(lpt=-1, split=-1, split_class=7)
+                ctx.set_option("host_sets", 0)
+                sc.close()
+    finally:
+        for b in bufs:
+            hip.lib.hipFree(b)
+
+
+
 def test_render_device_writes_device_buffers_on_the_callers_stream(ctx):
     """rtx_render_device (the entry point bench.py and a multi-GPU host use): outputs are device pointers, the work
     is queued on the caller's stream and nothing is copied.  Full frame with hit ids and stats, then asynchronous
