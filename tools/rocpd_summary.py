@@ -16,6 +16,22 @@ def main():
         print("%-60s %8s %14s %14s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"))
         for name, n, tot, avg, mn, mx in rows:
             print("%-60s %8d %14d %14.0f %14d %14d %6.2f%%" % (name[:60], n, tot, avg, mn, mx, 100.0 * tot / total))
+        # the same per launch SIZE (a whole frame, a band set and one rank's share are the same kernel), with the number of
+        # dispatches that ran beside another dispatch of the table (frames in flight on several streams: such a dispatch's
+        # duration includes its wait for wave slots, so only the rows with "beside 0" are per-launch kernel times)
+        try:
+            ds = cur.execute("select name, grid_x, start, end from kernels").fetchall()
+            groups = {}
+            for name, gx, st, en in ds:
+                beside = sum(1 for n2, g2, s2, e2 in ds if (n2, g2, s2, e2) != (name, gx, st, en) and s2 < en and e2 > st and e2 - s2 > 20000)
+                g = groups.setdefault((name, gx), [0, 0, 0, 1 << 62, 0])
+                g[0] += 1; g[1] += en - st; g[2] += 1 if beside else 0; g[3] = min(g[3], en - st); g[4] = max(g[4], en - st)
+            print("%-60s %10s %8s %14s %14s %14s %8s" % ("kernel, by launch size", "grid_x", "calls", "avg_ns", "min_ns", "max_ns", "beside"))
+            for (name, gx), g in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+                if "trace_shade" in name or "classify" in name:
+                    print("%-60s %10d %8d %14.0f %14d %14d %8d" % (name[:60], gx, g[0], g[1] / g[0], g[3], g[4], g[2]))
+        except sqlite3.Error as e:
+            print("(no per-size table: %s)" % e)
         try:
             cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
             if cols:
