@@ -632,7 +632,7 @@ static void release_scene_memory(rtx_scene* s) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    for (rtx_cost_entry& e : s->cost) { if (e.d_cost) (void)hipFree(e.d_cost); e = rtx_cost_entry(); }
+    for (rtx_cost_entry& e : s->cost) { if (e.d_cost) (void)hipFree(e.d_cost - RTX_COST_HEADER); e = rtx_cost_entry(); }
 }
 
 int rtx_init(int device, rtx_ctx** out) {
@@ -1081,9 +1081,20 @@ int enqueue_render(rtx_ctx* ctx, const rtx_scene* scene, const rtx_camera* cam, 
                 if (!ce) {
                     ce = lru;
                     if (ce->cap < (size_t)n_tiles) {
-                        if (ce->d_cost) (void)hipFree(ce->d_cost);         // (hipFree waits for the device: no launch still uses it)
+                        // The array carries its own capacity in a 16-byte header in FRONT of the costs (d_cost points behind it).  A
+                        // wave finds the array through a word of the counter block it adds into; renders queued on DIFFERENT caller
+                        // streams of one context share that block, so the tail of one frame can pick up the array of the frame
+                        // queued after it, of another size: the wave checks its tile index against the array it really holds.
+                        if (ce->d_cost) (void)hipFree(ce->d_cost - RTX_COST_HEADER);         // (hipFree waits for the device: no launch still uses it)
                         ce->d_cost = nullptr; ce->cap = 0;
-                        HIPCHK(ctx, hipMalloc((void**)&ce->d_cost, ((size_t)n_tiles + 4) * sizeof(int32_t)));      // (+ the time mode's 8-byte sum)
+                        int32_t* base = nullptr;
+                        HIPCHK(ctx, hipMalloc((void**)&base, ((size_t)n_tiles + RTX_COST_HEADER + 4) * sizeof(int32_t)));      // (+ the time mode's 8-byte sum)
+                        const int32_t header[RTX_COST_HEADER] = {n_tiles, 0, 0, 0};
+                        if (hipMemcpy(base, header, sizeof header, hipMemcpyHostToDevice) != hipSuccess) {
+                            (void)hipFree(base);
+                            return fail(ctx, RTX_E_DEVICE, "tile-cost array: header upload failed");
+                        }
+                        ce->d_cost = base + RTX_COST_HEADER;
                         ce->cap = n_tiles;
                     }
                     ce->hsize = cam->hsize; ce->vsize = cam->vsize; ce->band_first = bands.first; ce->band_stride = bands.stride; ce->max_depth = max_depth;

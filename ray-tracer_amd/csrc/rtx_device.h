@@ -211,6 +211,7 @@ struct RenderParams {
 // argument the pointer would be live — two scalar registers — through the whole kernel, also for scenes that never use it:
 // measured +2 % on the CSG workload.)  The reset launch that zeroes the block writes it.
 #define RTX_CNT_COST_PTR 31
+#define RTX_COST_HEADER 4            /* int32 words in front of a tile-cost array: [0] = the tiles it has room for (the writer's bound) */
 // The counters are replicated over RTX_CNT_SLOTS slots of RTX_CNT_STRIDE entries (256 bytes, own cache lines);
 // a wave adds into slot (block index mod RTX_CNT_SLOTS) and the host sums the slots.  With ONE set of
 // counters every wave's two ray-count atomics hit the same address and serialise at ~12 ns each: a floor of

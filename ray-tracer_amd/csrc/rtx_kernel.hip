@@ -262,6 +262,9 @@ __device__ __attribute__((noinline)) void tile_cost_tail(const unsigned long lon
     const unsigned long long word = __hip_atomic_load(&counters_base[RTX_CNT_COST_PTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!word) return;
     int32_t* const tile_cost = (int32_t*)(word & ~1ull);
+    // (the word may already name the array of the NEXT render queued on another stream of the context: never write past the
+    // capacity the array itself states)
+    if (tile_index >= __builtin_nontemporal_load(tile_cost - RTX_COST_HEADER)) return;
     int c;
     if (word & 1ull) {
         c = (int)((unsigned)__builtin_amdgcn_s_memrealtime() - (unsigned)__builtin_amdgcn_readfirstlane((int)t_start));

@@ -1,4 +1,4 @@
-"""One-off randomized sweep over the WAYS of rendering (not collected by pytest): python tests/sweep_entry_points.py [seeds [first]]
+"""One-off randomized sweep over the WAYS of rendering (not collected by pytest): python tests/sweep_entry_points.py [seeds [first [max_width max_height]]]
 on a GPU box.  Every scheduling feature of the library — tile lists from the probe or from measured costs, time-ordered tiles,
 split tiles, band sets on two lanes, the caller's stream, the no-alloc entry point, batches on four lanes, the band path of a
 loopback communicator with 2..8 ranks and frames in flight — must leave image, hit ids and ray counts exactly as the plain
@@ -13,7 +13,9 @@ DEFAULTS = dict(lpt=-1, split=-1, split_class=7, host_sets=0, probe_ahead=-1, co
 ctx = rtx.Context(0)
 hip = _Hip()
 bad = n = 0
-CAP = 640 * 400
+MAXW = int(sys.argv[3]) if len(sys.argv) > 3 else 640
+MAXH = int(sys.argv[4]) if len(sys.argv) > 4 else 400
+CAP = MAXW * MAXH
 d_rgb = hip.malloc(CAP * 3); d_hit = hip.malloc(CAP * 4)
 
 
@@ -39,7 +41,7 @@ def dev_image(W, H, with_hit=True):
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     rng = np.random.default_rng((int(sys.argv[2]) if len(sys.argv) > 2 else 8000) + seed)
     for i in range(60):
-        W, H = int(rng.integers(9, 640)), int(rng.integers(9, 400))
+        W, H = int(rng.integers(9, MAXW)), int(rng.integers(9, MAXH))
         depth = (5, 0, 1, 2, 3, 8, 7, 4)[i % 8]
         if i % 2:
             p = fuzz_api.plan(rng, W, H, big_csg=(i % 6 == 5))

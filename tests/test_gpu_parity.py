@@ -736,7 +736,11 @@ def test_in_stream_probe_then_probe_ahead_on_a_fresh_context():
     event (the events are created with the lane, not by the first ahead-frame), so the refill waits for frame 1.  Frames of
     alternating sizes (a set that belonged to another frame leaves tiles unrendered or renders them twice) queued back to back
     on one stream, then on two streams in turn, must equal the frames rendered one at a time.  Large enough that the stream is
-    still busy when the next frame is queued."""
+    still busy when the next frame is queued.
+    The two-stream leg is also the case the tile-cost arrays guard against: frames of one context on different streams share the
+    context's counter block, whose spare word names the cost array of the render queued LAST; the tail waves of a 9 090-tile
+    frame can therefore find the array of the 117-tile frame queued behind them - they check their tile index against the
+    capacity the array itself carries (rtx_device.h: RTX_COST_HEADER) and never write past it."""
     import ctypes as C
     import rtx
     hip = _Hip()
@@ -748,7 +752,7 @@ def test_in_stream_probe_then_probe_ahead_on_a_fresh_context():
     try:
         pw, _ = rtx.load_yaml(parity.scene_text("S4", 960, 544))
         rsc = ref.scene(pw)
-        for w, h in ((960, 544), (720, 808), (1280, 296)):
+        for w, h in ((960, 544), (720, 808), (1280, 296), (104, 72)):
             _, c = rtx.load_yaml(parity.scene_text("S4", w, h))
             cams.append(c[0]); wants.append(rsc.render(c[0], 5))
         rsc.close()
@@ -765,11 +769,12 @@ def test_in_stream_probe_then_probe_ahead_on_a_fresh_context():
                 streams.append(st)
             sts = streams[-n_streams:]
             outs = []
-            for k in range(7):
-                cam = cams[k % 3]
+            order = (0, 1, 2, 0, 1, 3, 1, 3, 2, 1, 3)
+            for k, i in enumerate(order):
+                cam = cams[i]
                 b = hip.malloc(cam.vsize * cam.hsize * 3, 0x55); bufs.append(b)
                 assert sc.render_device(cam, b.value, 0, 5, stream=sts[k % n_streams].value) is None
-                outs.append((k % 3, b))
+                outs.append((i, b))
             for st in sts:
                 assert hip.lib.hipStreamSynchronize(st) == 0
             fresh.poll(wait=True)
