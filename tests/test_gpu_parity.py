@@ -581,6 +581,18 @@ class _Hip:
         return out
 
 
+def test_every_way_of_rendering_agrees_on_random_scenes(ctx):
+    """tests/sweep_entry_points.py on 36 seeded random scenes (files and API-built graphs, a sixth with general-CSG roots, sizes up
+    to 400 x 240, depth budgets 0-8): tile lists from the probe and from measured costs, split tiles, time-ordered tiles, band sets,
+    frames queued on the caller's stream, the no-alloc entry point, a batch, frames in flight over a loopback communicator of 2-8
+    ranks - all with random option settings - leave image, hit ids and ray counts exactly as the plain render has them.  The
+    sweep itself runs by hand over thousands of scenes (profiles/r3j_entry_points_15000_tail.txt)."""
+    import sweep_entry_points
+    msgs = []
+    n, bad = sweep_entry_points.sweep(ctx, _Hip(), 1, 20261115, 400, 240, per_seed=36, log=msgs.append)
+    assert n >= 30 and bad == 0, msgs
+
+
 def test_general_csg_scenes_through_every_entry_point(ctx):
     """Scenes whose CSG roots exceed the fast kernels' bounds (general CSG kernels: lists in the device arena, one slot claimed per
     wave) through every way of rendering: rtx_render (one launch and band sets on two lanes, i.e. two launches claiming slots at
