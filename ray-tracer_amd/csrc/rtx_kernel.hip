@@ -1122,10 +1122,6 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                             ev[2] += pc; ev[3] += mx;             // (every lane adds the maximum: 64 x max per wave)
                         }
 #endif
-#ifdef RTX_TOUCH_NEXT
-                        int k_cur = 0;
-                        if (sc_cand != 0) { const int i0 = __builtin_ctz(sc_cand); k_cur = (sc.bodies + (op0 >= 0 ? op0 + i0 : sc.list_ops[child_base + i0]))->kind; }
-#endif
                         while (__any(sc_cand != 0)) {
                             DV(4, 1); DV(5, sc_cand != 0 ? 1 : 0);
                             if (sc_cand != 0) {
@@ -1133,17 +1129,7 @@ __global__ __launch_bounds__(64, CSG ? RTX_MIN_WAVES_CSG : RTX_MIN_WAVES) void t
                                 sc_cand &= sc_cand - 1;
                                 const int idx = op0 >= 0 ? op0 + i : sc.list_ops[child_base + i];
                                 const OpBody* gb = sc.bodies + idx;
-#ifdef RTX_TOUCH_NEXT
-                                // the KIND of this lane's next candidate is requested now and used in the next round: its record's
-                                // line is then on the way to the L1 while this candidate's test runs
-                                const int k1 = k_cur;
-                                if (sc_cand != 0) {
-                                    const int i2 = __builtin_ctz(sc_cand);
-                                    k_cur = (sc.bodies + (op0 >= 0 ? op0 + i2 : sc.list_ops[child_base + i2]))->kind;
-                                }
-#else
                                 const int k1 = gb->kind;
-#endif
                                 V3 lo = xf_point(gb->inv, gb->w33, gb->div != 0, po);
                                 V3 ld = xf_vector(gb->inv, pd);
                                 EV(RTX_EV_X_XFORM, 1);
