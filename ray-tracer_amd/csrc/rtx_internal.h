@@ -87,7 +87,8 @@ struct rtx_ctx {
 struct rtx_cost_entry {
     int hsize = 0, vsize = 0, band_first = 0, band_stride = 0, max_depth = 0;
     double cam_inverse[16] = {};
-    int32_t* d_cost = nullptr; size_t cap = 0;
+    int32_t* d_cost = nullptr; size_t cap = 0;   // costs[cap] (+ the time mode's 8-byte sum); the allocation starts RTX_COST_HEADER words earlier: [0] = cap,
+                                                 // which the writing wave checks its tile index against (rtx_kernel.hip: tile_cost_tail)
     bool valid = false;          // d_cost holds the costs of a frame of this view (queued or done)
     int age = 0;                 // frames since the last probe launch of this view
     unsigned long long used = 0; // for eviction: context-wide use counter at the last use
