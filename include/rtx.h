@@ -18,6 +18,10 @@
  * All matrices: 16 doubles, COLUMN-major (nalgebra storage: m[c*4+r]).
  * All arithmetic on the device is f64 with the reference's operation order.
  * Not thread-safe per context (the reference is single-threaded, main.rs:11-28).
+ * Renders queued on DIFFERENT streams of one context may overlap on the GPU: their
+ * images and hit ids are unaffected, but they share the context's counter block, so
+ * the rtx_stats of a render are meaningful only while no other render of that context
+ * is in flight.  Use one context per concurrent stream where the counts matter.
  */
 #ifndef RTX_H
 #define RTX_H
